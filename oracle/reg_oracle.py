@@ -1,0 +1,322 @@
+"""ORACLE (test infrastructure, not product): NumPy restatement of the reference
+3-D affine registration path -- matrix parameterisations, trilinear resample,
+correlation cost and the ``reg3d_affine1`` driver.
+
+PARITY STATUS: kernels **unpinned by upstream** (no tests / vectors in the
+reference; ``reg3d`` has no CPU path: src/api_reg.cpp:390-393) -- the restatement
+follows the CUDA source (citations below) with *exact float32* trilinear weights
+(the CUDA texture unit quantises weights to 8 fractional bits).
+The optimiser itself IS pinned: ``oracle/powell_oracle.py`` is checked bit-for-bit
+against ``oracle/_ref/libpowell_ref.so``, built from the reference's own
+``src/api_powell.c`` (oracle/Makefile).
+
+Registration layout: API names used directly, ``x`` fastest
+(src/api_reg.cpp:304, include/cukernel.cuh:549).  Volumes are ``[z][y][x]``
+float32 ndarrays; matrices are row-major 3x4 ``m[12]`` mapping a target voxel
+``(x, y, z)`` to a source coordinate.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+NDIM = 12
+
+
+# ---------------------------------------------------------------- matrices
+def p2matrix(x):
+    """src/api_subfunc.cu:557-562 -- 1-based 12-vector -> row-major 3x4."""
+    m = np.zeros(12, dtype=f32)
+    m[0], m[1], m[2], m[3] = x[4], x[5], x[6], x[1]
+    m[4], m[5], m[6], m[7] = x[7], x[8], x[9], x[2]
+    m[8], m[9], m[10], m[11] = x[10], x[11], x[12], x[3]
+    return m
+
+
+def matrix2p(m):
+    """src/api_subfunc.cu:569-574."""
+    x = np.zeros(13, dtype=f32)
+    x[1], x[2], x[3], x[4] = m[3], m[7], m[11], m[0]
+    x[5], x[6], x[7], x[8] = m[1], m[2], m[4], m[5]
+    x[9], x[10], x[11], x[12] = m[6], m[8], m[9], m[10]
+    return x
+
+
+def matrixmultiply(m1, m2):
+    """src/api_subfunc.cu:584-598 -- 3x4 affine product, float32, left-to-right."""
+    m1 = np.asarray(m1, dtype=f32)
+    m2 = np.asarray(m2, dtype=f32)
+    m = np.zeros(12, dtype=f32)
+    for r in range(3):
+        a, b, c, d = m1[4 * r], m1[4 * r + 1], m1[4 * r + 2], m1[4 * r + 3]
+        for col in range(4):
+            v = f32(f32(f32(a * m2[col]) + f32(b * m2[4 + col])) + f32(c * m2[8 + col]))
+            if col == 3:
+                v = f32(v + d)
+            m[4 * r + col] = v
+    return m
+
+
+def dof9tomatrix(p_dof, dof_num):
+    """src/api_subfunc.cu:715-824: M = [diag(a,b,c)|t] * Rz(alpha) * Rx(beta) * Ry(theta);
+    angles are degrees / 57.3 (double division, stored as float, :744-746)."""
+    x, y, z = f32(p_dof[1]), f32(p_dof[2]), f32(p_dof[3])
+    alpha = beta = theta = f32(0)
+    a = b = c = f32(1)
+    if dof_num >= 6:
+        alpha = f32(float(p_dof[4]) / 57.3)
+        beta = f32(float(p_dof[5]) / 57.3)
+        theta = f32(float(p_dof[6]) / 57.3)
+    if dof_num == 7:
+        a = b = c = f32(p_dof[7])
+    if dof_num == 9:
+        a, b, c = f32(p_dof[7]), f32(p_dof[8]), f32(p_dof[9])
+    t2 = np.zeros(12, dtype=f32)
+    t2[3], t2[7], t2[11] = x, y, z
+    t2[0], t2[5], t2[10] = a, b, c
+    ca, sa = f32(np.cos(alpha)), f32(np.sin(alpha))
+    t3 = np.array([ca, sa, 0, 0, -sa, ca, 0, 0, 0, 0, 1, 0], dtype=f32)  # Rz  :795-797
+    t1 = matrixmultiply(t2, t3)
+    cb, sb = f32(np.cos(beta)), f32(np.sin(beta))
+    t3 = np.array([1, 0, 0, 0, 0, cb, sb, 0, 0, -sb, cb, 0], dtype=f32)  # Rx  :805-807
+    t2 = matrixmultiply(t1, t3)
+    ct, st = f32(np.cos(theta)), f32(np.sin(theta))
+    t3 = np.array([ct, 0, -st, 0, 0, 1, 0, 0, st, 0, ct, 0], dtype=f32)  # Ry  :815-817
+    return matrixmultiply(t2, t3)
+
+
+def rot2matrix(theta, sx, sy, sz, rot_axis):
+    """src/api_subfunc.cu:626-713 (used by mip3dgpu).  Integer halves ``s / 2``."""
+    theta = f32(theta)
+    t1 = np.zeros(12, dtype=f32)
+    t2 = np.zeros(12, dtype=f32)
+    t3 = np.zeros(12, dtype=f32)
+    t1[0] = t1[5] = t1[10] = 1
+    t3[0] = t3[5] = t3[10] = 1
+    c, s = f32(np.cos(theta)), f32(np.sin(theta))
+    if rot_axis == 1:
+        t1[7], t1[11] = sy // 2, sz // 2
+        t2[:] = [1, 0, 0, 0, 0, c, s, 0, 0, -s, c, 0]
+        s_new = int(np.round(np.sqrt(float(sy * sy + sz * sz))))
+        t3[7] = t3[11] = int(-s_new / 2)
+    elif rot_axis == 2:
+        t1[3], t1[11] = sx // 2, sz // 2
+        t2[:] = [c, 0, -s, 0, 0, 1, 0, 0, s, 0, c, 0]
+        s_new = int(np.round(np.sqrt(float(sx * sx + sz * sz))))
+        t3[3] = t3[11] = int(-s_new / 2)
+    elif rot_axis == 3:
+        t1[3], t1[7] = sx // 2, sy // 2
+        t2[:] = [c, s, 0, 0, -s, c, 0, 0, 0, 0, 1, 0]
+        s_new = int(np.round(np.sqrt(float(sx * sx + sy * sy))))
+        t3[3] = t3[7] = int(-s_new / 2)
+    return matrixmultiply(matrixmultiply(t1, t2), t3)
+
+
+def checkmatrix(m, sx, sy, sz):
+    """src/api_reg.cpp:247-262."""
+    m = np.asarray(m, dtype=f32)
+    ok = True
+    lo, up, slo, sup, ratio = f32(0.5), f32(1.4), f32(2), f32(4), f32(0.8)
+    if m[0] < lo or m[0] > up or m[5] < lo or m[5] > up or m[10] < lo or m[10] > up:
+        ok = False
+    ssum = f32(f32(m[0] + m[5]) + m[10])
+    if ssum < slo or ssum > sup:
+        ok = False
+    if abs(m[3]) > f32(ratio * f32(sx)) or abs(m[7]) > f32(ratio * f32(sy)) or abs(m[11]) > f32(ratio * f32(sz)):
+        ok = False
+    return ok
+
+
+# ---------------------------------------------------------------- sampling
+def _coords(m, shape):
+    """Texture coordinates of every target voxel, float32, evaluated exactly as
+    ``d_aff[0]*ix + d_aff[1]*iy + d_aff[2]*iz + d_aff[3] + 0.5`` left to right without
+    FMA contraction (include/cukernel.cuh:510-512, 539-541)."""
+    sz, sy, sx = shape
+    m = np.asarray(m, dtype=f32)
+    ix = np.arange(sx, dtype=f32)[None, None, :]
+    iy = np.arange(sy, dtype=f32)[None, :, None]
+    iz = np.arange(sz, dtype=f32)[:, None, None]
+    half = f32(0.5)
+    out = []
+    for r in range(3):
+        t = (m[4 * r] * ix + m[4 * r + 1] * iy)
+        t = t + m[4 * r + 2] * iz
+        t = t + m[4 * r + 3]
+        t = t + half
+        out.append(np.broadcast_to(t, shape).astype(f32))
+    return out  # tx, ty, tz
+
+
+def _trilinear(src, tx, ty, tz):
+    """Linear texture fetch with unnormalised coordinates, texel centres at +0.5,
+    neighbour indices clamped to the edge (BindTexture, src/api_subfunc.cu:885-895;
+    wrap degrades to clamp for unnormalised coordinates).  Exact float32 weights:
+    v = (1-w)*q0 + w*q1 along x, then y, then z (itrilerp2, :1075-1091)."""
+    s2z, s2y, s2x = src.shape
+    half = f32(0.5)
+    one = f32(1)
+
+    def split(t, n):
+        b = t - half
+        i0f = np.floor(b)
+        w1 = (b - i0f).astype(f32)
+        w0 = (one - w1).astype(f32)
+        i0 = i0f.astype(np.int64)
+        i1 = i0 + 1
+        return np.clip(i0, 0, n - 1), np.clip(i1, 0, n - 1), w0, w1
+
+    x0, x1, wx0, wx1 = split(tx, s2x)
+    y0, y1, wy0, wy1 = split(ty, s2y)
+    z0, z1, wz0, wz1 = split(tz, s2z)
+
+    def g(zz, yy, xx):
+        return src[zz, yy, xx]
+
+    c00 = wx0 * g(z0, y0, x0) + wx1 * g(z0, y0, x1)
+    c01 = wx0 * g(z0, y1, x0) + wx1 * g(z0, y1, x1)
+    c10 = wx0 * g(z1, y0, x0) + wx1 * g(z1, y0, x1)
+    c11 = wx0 * g(z1, y1, x0) + wx1 * g(z1, y1, x1)
+    c0 = wy0 * c00 + wy1 * c01
+    c1 = wy0 * c10 + wy1 * c11
+    return (wz0 * c0 + wz1 * c1).astype(f32)
+
+
+def affine_transform(src, m, out_shape):
+    """affinetransformkernel, include/cukernel.cuh:501-524: non-strict lower bound
+    ``0 <= t < s2`` on the +0.5 coordinates, 0 outside."""
+    src = np.asarray(src, dtype=f32)
+    tx, ty, tz = _coords(m, out_shape)
+    s2z, s2y, s2x = src.shape
+    valid = ((tx >= 0) & (tx < f32(s2x)) & (ty >= 0) & (ty < f32(s2y)) & (tz >= 0) & (tz < f32(s2z)))
+    v = _trilinear(src, tx, ty, tz)
+    return np.where(valid, v, f32(0)).astype(f32)
+
+
+def corr_sums(target, src, m):
+    """corrkernel, include/cukernel.cuh:526-556: strict ``0 < t < s2``; returns
+    (sum s*s, sum s*t) accumulated in float64."""
+    target = np.asarray(target, dtype=f32)
+    src = np.asarray(src, dtype=f32)
+    tx, ty, tz = _coords(m, target.shape)
+    s2z, s2y, s2x = src.shape
+    valid = ((tx > 0) & (tx < f32(s2x)) & (ty > 0) & (ty < f32(s2y)) & (tz > 0) & (tz < f32(s2z)))
+    s = np.where(valid, _trilinear(src, tx, ty, tz), f32(0)).astype(np.float64)
+    ss = float(np.sum(s * s))
+    st = float(np.sum(s * target.astype(np.float64)))
+    return ss, st
+
+
+def corrfunc(target, sd_t, src, m):
+    """corrfunc, src/api_subfunc.cu:954-988."""
+    ss, st = corr_sums(target, src, m)
+    if np.sqrt(ss) == 0:
+        return f32(-2.0)
+    return f32(f32(st / np.sqrt(ss)) / f32(sd_t))
+
+
+def mean_subtract(a):
+    """addvaluegpu(-float(sum)/float(N)), src/api_subfunc.cu:2840,2844,2860."""
+    a = np.asarray(a, dtype=f32)
+    s = float(np.sum(a, dtype=np.float64))
+    mean = f32(f32(s) / f32(a.size))
+    return (a + (-mean)).astype(f32), s
+
+
+# ---------------------------------------------------------------- driver
+class Reg3dAffine:
+    """reg3d_affine1, src/api_subfunc.cu:2733-2994, with Powell supplied by
+    ``powell_fn(p, xi, n, ftol, func, counter, it_limit) -> (iter, fret)`` operating on
+    1-based float32 arrays (oracle/powell_oracle.py or the `_ref` build)."""
+
+    def __init__(self, powell_fn):
+        self.powell = powell_fn
+
+    def run(self, target, source, aff_method, flag_tmx=False, i_tmx=None, ftol=1e-4, it_limit=3000):
+        target = np.asarray(target, dtype=f32)
+        source = np.asarray(source, dtype=f32)
+        shape = target.shape
+        records = np.zeros(11, dtype=f32)
+        i_tmx = None if i_tmx is None else np.asarray(i_tmx, dtype=f32).copy()
+        if aff_method == 0:  # :2767-2781
+            if flag_tmx:
+                return affine_transform(source, i_tmx, shape), i_tmx, records
+            ident = np.zeros(12, dtype=f32)
+            ident[0] = ident[5] = ident[10] = 1
+            return source.copy(), ident, records
+
+        aff_init = np.zeros(12, dtype=f32)
+        aff_init[0] = aff_init[5] = aff_init[10] = 1
+        xi = np.zeros((NDIM + 1, NDIM + 1), dtype=f32)
+        for i in range(1, NDIM + 1):
+            xi[i, i] = 1
+        xi9 = np.zeros((10, 10), dtype=f32)
+        p9 = np.zeros(10, dtype=f32)
+        src_work = source
+        if flag_tmx:
+            if aff_method == 5:
+                aff_init = i_tmx.copy()  # :2820
+            else:
+                src_work = affine_transform(source, i_tmx, shape)  # :2824
+        if aff_method != 5:
+            for i in range(1, 10):
+                xi9[i, i] = 1
+            p9[7] = p9[8] = p9[9] = 1  # :2832-2835
+        src_ms, _ = mean_subtract(src_work)  # :2838-2845
+        if np.sqrt(float(np.sum(src_ms.astype(np.float64) ** 2))) == 0:
+            raise ValueError("SD of image 2 is zero")  # :2853-2856
+        tgt_ms, _ = mean_subtract(target)  # :2859-2860
+        sd_t = f32(np.sqrt(float(np.sum((tgt_ms * tgt_ms).astype(np.float64)))))  # :2861-2863
+        if sd_t == 0:
+            raise ValueError("SD of image 1 is zero")
+
+        state = {"aff": None, "dof9": False, "dof": 12}
+        counter = [0]
+
+        def costfunc(x):  # :2377-2388
+            if state["dof9"]:
+                state["aff"] = dof9tomatrix(x, state["dof"])
+            else:
+                state["aff"] = p2matrix(x)
+            c = corrfunc(tgt_ms, sd_t, src_ms, state["aff"])
+            counter[0] += 1
+            return f32(-c)
+
+        p = matrix2p(aff_init)  # :2879
+        records[1] = -costfunc(p)  # :2881
+        counter[0] = 0  # :2888
+        fret = f32(0)
+
+        def run9(dof, tol):
+            state["dof9"], state["dof"] = True, dof
+            return self.powell(p9, xi9, dof, f32(tol), costfunc, counter, it_limit)
+
+        def run12(tol):
+            state["dof9"], state["dof"] = False, 12
+            return self.powell(p, xi, 12, f32(tol), costfunc, counter, it_limit)
+
+        if aff_method in (1, 2, 3, 4):  # :2890-2909
+            _, fret = run9({1: 3, 2: 6, 3: 7, 4: 9}[aff_method], ftol)
+        elif aff_method == 5:  # :2910-2914
+            _, fret = run12(ftol)
+        elif aff_method == 6:  # :2915-2929
+            _, fret = run9(6, 0.01)
+            records[2] = -fret
+            p = matrix2p(state["aff"])  # the LAST evaluated matrix (App. C quirk)
+            _, fret = run12(ftol)
+        elif aff_method == 7:  # :2930-2954
+            _, fret = run9(3, 0.01)
+            _, fret = run9(6, 0.01)
+            _, fret = run9(9, 0.005)
+            records[2] = -fret
+            p = matrix2p(state["aff"])
+            _, fret = run12(ftol)
+        else:
+            raise ValueError("wrong affMethod")
+        aff = state["aff"]
+        if flag_tmx and aff_method != 5:
+            aff = matrixmultiply(i_tmx, aff)  # :2958-2961
+        records[3] = -fret
+        records[5] = counter[0]
+        reg = affine_transform(source, aff, shape)  # raw source  :2974-2977
+        return reg, aff, records
