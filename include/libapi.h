@@ -1,0 +1,116 @@
+/*
+ * libapi.h -- public C API of the MI355X-native build of the microImageLib hot path.
+ *
+ * Drop-in for the reference's include/libapi.h: every symbol below has the name,
+ * argument list, argument meaning and return convention of the reference prototype
+ * cited next to it, so the reference CLIs (deconSingleView, deconDualView, reg3D,
+ * spimFusion, spimFusionBatch, checkGPUDevice) link against this library unchanged.
+ * All functions have C linkage.  The reference CLIs include this header from inside
+ * an `extern "C" { }` block; nesting the linkage specification is harmless.
+ *
+ * Conventions shared by all volume arguments
+ *   - host pointers, caller-owned, float32, TIFF order: idx = x + sx*(y + sy*z);
+ *   - `imSize` / `psfSize` = {sx (fastest), sy, sz};
+ *   - the library allocates and frees every device buffer inside the call.
+ *
+ * Differences from the reference, all deliberate:
+ *   - gpuMemMode 0 (the FFTW CPU path) is not provided: the call returns non-zero
+ *     and prints a message, as the reference itself does for CPU registration
+ *     (src/api_reg.cpp:390-393).  gpuMemMode 2 is executed as mode 1 (288 GB HBM).
+ *   - timings in the records arrays are wall-clock seconds, not clock() CPU time.
+ */
+#ifndef MICROIMAGELIB_AMD_LIBAPI_H
+#define MICROIMAGELIB_AMD_LIBAPI_H
+
+#ifdef __cplusplus
+extern "C" {
+#else
+#include <stdbool.h>
+#endif
+
+/* ------------------------------------------------------------------ file I/O
+ * reference: include/libapi.h:12-18, src/apifunc.cpp:53-326 */
+char *concat(int count, ...);
+bool fexists(const char *filename);
+/* returns bits per sample; tifSize = {width, height, #slices} */
+unsigned short gettifinfo(char tifdir[], unsigned int *tifSize);
+void readtifstack(float *h_Image, char *tifdir, unsigned int *imsize);
+void writetifstack(char *tifdir, float *h_Image, unsigned int *imsize, unsigned short bitPerSample);
+void readtifstack_16to16(unsigned short *h_Image, char *tifdir, unsigned int *imsize);
+void writetifstack_16to16(char *tifdir, unsigned short *h_Image, unsigned int *imsize);
+
+/* ------------------------------------------------------------------ device query
+ * reference: include/libapi.h:21, src/apifunc.cpp:328-394 */
+void queryDevice();
+
+/* ------------------------------------------------------------------ affine transform
+ * reference: include/libapi.h:28-32, src/api_reg.cpp:58-112, 247-262
+ * iTmx: row-major 3x4, maps an OUTPUT voxel (x,y,z) to a SOURCE coordinate. */
+bool checkmatrix(float *iTmx, long long int sx, long long int sy, long long int sz);
+int atrans3dgpu(float *h_reg, float *iTmx, float *h_img2, unsigned int *imSize1, unsigned int *imSize2,
+                int deviceNum);
+int atrans3dgpu_16bit(unsigned short *h_reg, float *iTmx, unsigned short *h_img2, unsigned int *imSize1,
+                      unsigned int *imSize2, int deviceNum);
+
+/* ------------------------------------------------------------------ 3-D registration
+ * reference: include/libapi.h:35-39, src/api_reg.cpp:264-652
+ *   regChoice  0 apply matrix | 1 phasor | 2 affine | 3 phasor->affine | 4 2-D MIP->affine
+ *   affMethod  0 none | 1 3-DOF | 2 6 | 3 7 | 4 9 | 5 12 | 6 6->12 | 7 3->6->9->12
+ *   records[11]: [0] mode, [1] initial ZNCC, [2] intermediate, [3] final, [4] ms/eval,
+ *                [5] #evaluations, [6] optimisation s, [7] total s, [8..10] free MB
+ * returns 0 ok; 1 bad regChoice/gpuMemMode; -1 unsupported mode. */
+int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1, unsigned int *imSize2,
+          int regChoice, int affMethod, bool inputTmx, float FTOL, int itLimit, int deviceNum, int gpuMemMode,
+          bool verbose, float *records);
+int reg_3dgpu(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1,
+              unsigned int *imSize2, int regMethod, int inputTmx, float FTOL, int itLimit, int subBgTrigger,
+              int deviceNum, float *regRecords);
+/* reference: include/libapi.h:24-25, src/api_reg.cpp:115-244 */
+int reg2d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1, unsigned int *imSize2,
+          int regChoice, bool flagTmx, float FTOL, int itLimit, int deviceNum, int gpuMemMode, bool verbose,
+          float *records);
+
+/* ------------------------------------------------------------------ 3-D deconvolution
+ * reference: include/libapi.h:42-46, src/api_decon.cpp:53-331, 333-704
+ *   initialFlag   true: constant initial estimate (the reference uses the SUM of the image)
+ *   gpuMemMode    -1 auto | 1 | 2 (run as 1) | 0 unsupported here
+ *   deconRecords[10]: [0] mode used, [1..5] free MB snapshots, [6] init s, [7] unused,
+ *                     [8] decon s, [9] total s
+ *   flagUnmatch   true: h_psf_bp* are explicit back projectors; false: flipped PSF
+ * returns 0 ok; 1 (single) / -1 (dual) on a bad gpuMemMode, like the reference. */
+int decon_singleview(float *h_decon, float *h_img, unsigned int *imSize, float *h_psf, unsigned int *psfSize,
+                     bool initialFlag, int itNumForDecon, int deviceNum, int gpuMemMode, bool verbose,
+                     float *deconRecords, bool flagUnmatch, float *h_psf_bp);
+int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsigned int *imSize, float *h_psf1,
+                   float *h_psf2, unsigned int *psfSize, bool initialFlag, int itNumForDecon, int deviceNum,
+                   int gpuMemMode, bool verbose, float *deconRecords, bool flagUnmatch, float *h_psf_bp1,
+                   float *h_psf_bp2);
+
+/* reference: include/libapi.h:49-51, src/api_decon.cpp:988-1266.  Upstream this entry point is
+ * dead code (its guard at :1133 always returns 1); kept only so the symbol resolves. */
+int fusion_dualview(float *h_decon, float *h_reg, float *h_prereg1, float *h_prereg2, float *iTmx, float *h_img1,
+                    float *h_img2, unsigned int *imSizeIn1, unsigned int *imSizeIn2, float *pixelSize1,
+                    float *pixelSize2, int imRotation, bool flagTmx, int regChoice, float FTOL, int itLimit,
+                    float *h_psf1, float *h_psf2, unsigned int *psfSizeIn, int itNumForDecon, int deviceNum,
+                    int gpuMemMode, bool verbose, float *fusionRecords, bool flagUnmatch, float *h_psf_bp1,
+                    float *h_psf_bp2);
+
+/* ------------------------------------------------------------------ projections, resize, rotate
+ * reference: include/libapi.h:54-68, src/apifunc.cpp:397-644 */
+int mp2dgpu(float *h_MP, unsigned int *sizeMP, float *h_img, unsigned int *sizeImg, bool flagZProj, bool flagXProj,
+            bool flagYProj);
+int mp3dgpu(float *h_MP, unsigned int *sizeMP, float *h_img, unsigned int *sizeImg, bool flagXaxis, bool flagYaxis,
+            int projectNum);
+int mip3dgpu(float *h_MP, unsigned int *sizeMP, float *h_img, unsigned int *sizeImg, int rAxis,
+             long long int projectNum);
+int alignsize3d(float *h_odata, float *h_idata, long long int sx, long long int sy, long long int sz,
+                long long int sx2, long long int sy2, long long int sz2, int gpuMemMode);
+int imresize3d(float *h_odata, float *h_idata, long long int sx1, long long int sy1, long long int sz1,
+               long long int sx2, long long int sy2, long long int sz2, int deviceNum);
+int imoperation3D(float *h_odata, unsigned int *sizeOut, float *h_idata, unsigned int *sizeIn, int opChoice,
+                  int deviceNum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICROIMAGELIB_AMD_LIBAPI_H */

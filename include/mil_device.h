@@ -1,0 +1,96 @@
+/*
+ * mil_device.h -- thin device-pointer C ABI underneath libapi.h.
+ *
+ * libapi.h keeps the reference's host-pointer contract (every call uploads, computes,
+ * downloads).  A host that keeps its volumes resident in HBM -- a time-lapse batch
+ * driver, the benchmark, the parity tests -- binds these instead: plain pointers and
+ * sizes, a HIP stream passed as `void *` (NULL = the engine's own stream), `int`
+ * status (0 = ok).  Each entry names the reference interface it replaces
+ * (paths relative to the reference tree).
+ *
+ * Volumes are float32, x fastest: idx = x + nx*(y + ny*z).  Half spectra are
+ * interleaved complex64, dims [nz][ny][nx/2+1], unnormalised transforms.
+ */
+#ifndef MICROIMAGELIB_AMD_MIL_DEVICE_H
+#define MICROIMAGELIB_AMD_MIL_DEVICE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library / device ---------------------------------------------------- */
+const char *mil_version(void);
+int mil_device_count(void);
+int mil_set_device(int device);               /* cudaSetDevice(deviceNum), src/api_decon.cpp:102 */
+int mil_snap_transform_size(int n);           /* snapTransformSize, src/api_subfunc.cu:57-87 */
+
+/* ---- RL element-wise kernels (in place) ----------------------------------- */
+int mil_rl_ratio(float *d_T, const float *d_A, size_t n, void *stream);               /* div3Dgpu  src/api_subfunc.cu:333 */
+int mil_rl_update(float *d_E, const float *d_T, size_t n, float eps, void *stream);   /* multi3Dgpu :281 + maxvalue3Dgpu :477 */
+int mil_cmul(void *d_S, const void *d_OTF, size_t n_complex, void *stream);           /* multicomplex3Dgpu :305 */
+int mil_sum_f64(const float *d_in, size_t n, double *h_out, void *stream);            /* sum3Dgpu :386 */
+
+/* ---- geometry ------------------------------------------------------------- */
+/* padPSFgpu :1691 (+ multivaluegpu scale, + flipgpu :1680 when flip != 0); psf dims <= box dims */
+int mil_pad_psf(float *d_out, const float *d_psf, int fx, int fy, int fz, int px, int py, int pz, float scale,
+                int flip, void *stream);
+int mil_pad_stack(float *d_out, const float *d_in, int fx, int fy, int fz, int sx, int sy, int sz, void *stream);  /* padstackgpu :1713 */
+int mil_crop_stack(float *d_out, const float *d_in, int sx, int sy, int sz, int fx, int fy, int fz, void *stream); /* cropgpu :1736 */
+int mil_align_size(float *d_out, const float *d_in, int ox, int oy, int oz, int ix, int iy, int iz, void *stream); /* alignsize3Dgpu :1779 */
+int mil_flip3(float *d_out, const float *d_in, int nx, int ny, int nz, void *stream);                             /* flipgpu :1680 */
+int mil_rot_y90(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream);            /* rotbyyaxis :528 */
+int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream);     /* maxprojection :490 */
+
+/* ---- deconvolution engine -------------------------------------------------- */
+typedef struct mil_decon mil_decon;
+/* FFT box (nx,ny,nz): rocFFT plans + scratch allocated once (replaces the per-call
+ * cufftPlan3d / cudaMalloc of decon_*_OTF1, src/api_subfunc.cu:3376-3396). */
+int mil_decon_create(mil_decon **out, int nx, int ny, int nz, void *stream);
+void mil_decon_destroy(mil_decon *e);
+size_t mil_decon_real_count(const mil_decon *e);
+size_t mil_decon_spectrum_count(const mil_decon *e);
+/* genOTFgpu :3269 (flip != 0 applies flipgpu first: matched back projector) */
+int mil_decon_gen_otf(mil_decon *e, void *d_otf, const float *d_psf, int px, int py, int pz, int flip);
+int mil_decon_init_single(mil_decon *e, float *d_A, float *d_E, int const_init);             /* :3380-3388 */
+int mil_decon_init_dual(mil_decon *e, float *d_A, float *d_B, float *d_E, int const_init);   /* :3606-3618 */
+/* the RL loops, decon_singleview_OTF1 :3404-3416 / decon_dualview_OTF1 :3634-3660; asynchronous */
+int mil_decon_run_single(mil_decon *e, float *d_E, const float *d_A, const void *d_otf, const void *d_otf_bp,
+                         int iters);
+int mil_decon_run_dual(mil_decon *e, float *d_E, const float *d_A, const float *d_B, const void *d_otf1,
+                       const void *d_otf2, const void *d_otf_bp1, const void *d_otf_bp2, int iters);
+int mil_decon_sync(mil_decon *e);
+/* HIP-event timers bracketing kernel families on the engine's stream.
+ * which: 0 rl_update, 1 rl_ratio, 2 cmul, 3 rocFFT executes. */
+int mil_decon_timer_enable(mil_decon *e, int which, int enable);
+int mil_decon_timer_read(mil_decon *e, int which, double *total_ms, size_t *launches); /* syncs, then resets */
+
+/* ---- registration ---------------------------------------------------------- */
+/* affineTransform + affinetransformkernel, src/api_subfunc.cu:943, include/cukernel.cuh:501 */
+int mil_affine_resample(float *d_out, const float *d_src, int ox, int oy, int oz, int sx, int sy, int sz,
+                        const float *m12, void *stream);
+/* corrkernel + 2x sumgpu1D, include/cukernel.cuh:526, src/api_subfunc.cu:954-988: h_out = {sum s*s, sum s*t} */
+int mil_corr_sums(const float *d_target, const float *d_src, int tx, int ty, int tz, int sx, int sy, int sz,
+                  const float *m12, double *h_out, void *stream);
+/* reg3d_affine1, src/api_subfunc.cu:2733-2994, on device-resident volumes of equal size */
+int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
+                     int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records,
+                     void *stream);
+
+/* ---- host-side pieces of the path (no GPU needed) --------------------------- */
+/* powell(), src/api_powell.c:305-360.  0-based: p[n]; xi row-major with leading dimension ld,
+ * column j = direction j.  f is called with a 0-based parameter vector. */
+typedef float (*mil_cost_fn)(const float *x, void *user);
+int mil_powell(float *p, float *xi, int ld, int n, float ftol, int *iter, float *fret, mil_cost_fn f, void *user,
+               int *totalIt, int itLimit);
+void mil_p2matrix(float *m12, const float *p12);                    /* p2matrix :557 (0-based p) */
+void mil_matrix2p(float *p12, const float *m12);                    /* matrix2p :569 */
+void mil_dof9tomatrix(float *m12, const float *p9, int dofNum);     /* dof9tomatrix :715 (0-based p) */
+void mil_matrixmultiply(float *m, const float *m1, const float *m2);/* matrixmultiply :584 */
+void mil_rot2matrix(float *m12, float theta, long long sx, long long sy, long long sz, int rotAxis); /* :626 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICROIMAGELIB_AMD_MIL_DEVICE_H */

@@ -1,0 +1,231 @@
+// Hand-written gfx950 kernels for the registration hot path: explicit trilinear
+// resampling (gfx950 has no texture unit -- hipcc rejects tex3D for this target)
+// and the fused interpolate + correlate + reduce cost kernel that Powell drives.
+//
+// Semantics restated from the reference CUDA kernels (include/cukernel.cuh:501-556):
+//   t = M*(x,y,z,1) + 0.5 evaluated left to right in float32 (no FMA: this file is
+//   built with -ffp-contract=off), validity window on t, then a linear "texture"
+//   fetch at t with texel centres at +0.5 and neighbour indices clamped to the edge.
+// Interpolation weights are exact float32 (CUDA's texture unit quantises them to 8
+// fractional bits; see DESIGN.md "Registration numerics").
+//
+// Both kernels are gather/HBM-bound: per target voxel one coalesced target read and
+// eight source gathers whose footprint, for the near-identity matrices registration
+// visits, is a sheared box only slightly larger than the target tile -- so the gathers
+// hit L1/L2 and HBM traffic stays ~ (target + source) bytes.
+#include "kernels.h"
+
+namespace mil {
+namespace k {
+
+namespace {
+
+constexpr int kTileX = 64;   // one wave spans 64 consecutive x -> coalesced target reads
+constexpr int kTileY = 4;    // 4 waves per workgroup
+constexpr int kCorrZ = 16;   // z-steps per thread in the cost kernel
+constexpr int kBlockThreads = kTileX * kTileY;
+
+struct AffineArgs {
+    float m[12];
+    int tx, ty, tz;  // target / output dims
+    int sx, sy, sz;  // source dims
+};
+
+__device__ __forceinline__ float coord(const float *r, float ix, float iy, float iz) {
+    float t = r[0] * ix + r[1] * iy;  // d_aff[0]*ix + d_aff[1]*iy + d_aff[2]*iz + d_aff[3] + 0.5
+    t = t + r[2] * iz;
+    t = t + r[3];
+    return t + 0.5f;
+}
+
+struct Tap {
+    int i0, i1;
+    float w0, w1;
+};
+
+__device__ __forceinline__ Tap make_tap(float t, int n) {
+    float b = t - 0.5f;
+    float f = floorf(b);
+    Tap p;
+    p.w1 = b - f;
+    p.w0 = 1.0f - p.w1;
+    int i = (int)f;
+    int j = i + 1;
+    p.i0 = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    p.i1 = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+    return p;
+}
+
+__device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int sx, int sy, int sz, float tx, float ty,
+                                              float tz) {
+    Tap X = make_tap(tx, sx), Y = make_tap(ty, sy), Z = make_tap(tz, sz);
+    const size_t row = (size_t)sx, plane = (size_t)sx * sy;
+    const float *p00 = src + Z.i0 * plane + Y.i0 * row;
+    const float *p01 = src + Z.i0 * plane + Y.i1 * row;
+    const float *p10 = src + Z.i1 * plane + Y.i0 * row;
+    const float *p11 = src + Z.i1 * plane + Y.i1 * row;
+    float c00 = X.w0 * p00[X.i0] + X.w1 * p00[X.i1];
+    float c01 = X.w0 * p01[X.i0] + X.w1 * p01[X.i1];
+    float c10 = X.w0 * p10[X.i0] + X.w1 * p10[X.i1];
+    float c11 = X.w0 * p11[X.i0] + X.w1 * p11[X.i1];
+    float c0 = Y.w0 * c00 + Y.w1 * c01;
+    float c1 = Y.w0 * c10 + Y.w1 * c11;
+    return Z.w0 * c0 + Z.w1 * c1;
+}
+
+// affinetransformkernel, reference include/cukernel.cuh:501-524 (window 0 <= t < s2).
+__global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restrict__ out,
+                                                               const float *__restrict__ src, AffineArgs a) {
+    const int x = blockIdx.x * kTileX + (threadIdx.x & (kTileX - 1));
+    const int y = blockIdx.y * kTileY + (threadIdx.x / kTileX);
+    const int z = blockIdx.z;
+    if (x >= a.tx || y >= a.ty) return;
+    const float ix = (float)x, iy = (float)y, iz = (float)z;
+    const float tx = coord(a.m + 0, ix, iy, iz);
+    const float ty = coord(a.m + 4, ix, iy, iz);
+    const float tz = coord(a.m + 8, ix, iy, iz);
+    float v = 0.0f;
+    if (tx >= 0 && tx < (float)a.sx && ty >= 0 && ty < (float)a.sy && tz >= 0 && tz < (float)a.sz)
+        v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
+    out[(size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z)] = v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// corrkernel, reference include/cukernel.cuh:526-556 (strict window 0 < t < s2), fused with
+// the two reductions the reference does in separate launches (sumgpu1D, src/api_subfunc.cu:970-971).
+// Each workgroup owns a 64 x 4 x kCorrZ target tile; float64 accumulators per lane, DPP/shuffle
+// wave reduction, LDS across the 4 waves, one (ss, st) partial per workgroup.
+__global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__restrict__ tgt,
+                                                           const float *__restrict__ src, AffineArgs a,
+                                                           double *__restrict__ partials, int nblocks) {
+    __shared__ double lds[2 * kTileY];
+    const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
+    const int x = blockIdx.x * kTileX + lane;
+    const int y = blockIdx.y * kTileY + wave;
+    const int z0 = blockIdx.z * kCorrZ;
+    double ss = 0.0, st = 0.0;
+    if (x < a.tx && y < a.ty) {
+        const float ix = (float)x, iy = (float)y;
+        const int z1 = (z0 + kCorrZ < a.tz) ? z0 + kCorrZ : a.tz;
+        const float *tp = tgt + (size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z0);
+        const size_t tstep = (size_t)a.tx * a.ty;
+        for (int z = z0; z < z1; ++z, tp += tstep) {
+            const float iz = (float)z;
+            const float tx = coord(a.m + 0, ix, iy, iz);
+            const float ty = coord(a.m + 4, ix, iy, iz);
+            const float tz = coord(a.m + 8, ix, iy, iz);
+            float sv = 0.0f;
+            if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
+                sv = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
+            const float tv = *tp;
+            ss += (double)sv * (double)sv;
+            st += (double)sv * (double)tv;
+        }
+    }
+    ss = wave_sum(ss);
+    st = wave_sum(st);
+    if (lane == 0) {
+        lds[wave] = ss;
+        lds[kTileY + wave] = st;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTileY; ++w) {
+            a0 += lds[w];
+            a1 += lds[kTileY + w];
+        }
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        partials[b] = a0;
+        partials[nblocks + b] = a1;
+    }
+}
+
+constexpr int kFinalThreads = 1024;
+__global__ __launch_bounds__(kFinalThreads) void corr_final_kernel(const double *__restrict__ partials, int count,
+                                                                 double *__restrict__ out) {
+    __shared__ double lds[2 * (kFinalThreads / 64)];
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = threadIdx.x; i < count; i += kFinalThreads) {
+        a0 += partials[i];
+        a1 += partials[count + i];
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        lds[wave] = a0;
+        lds[kFinalThreads / 64 + wave] = a1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r0 = 0.0, r1 = 0.0;
+        for (int w = 0; w < kFinalThreads / 64; ++w) {
+            r0 += lds[w];
+            r1 += lds[kFinalThreads / 64 + w];
+        }
+        out[0] = r0;
+        out[1] = r1;
+    }
+}
+
+AffineArgs make_args(Dims t, Dims s, const Affine12 &m) {
+    if (t.nx <= 0 || t.ny <= 0 || t.nz <= 0 || s.nx <= 0 || s.ny <= 0 || s.nz <= 0)
+        throw Error(-1, "affine kernel: empty volume");
+    if (t.nx > (1 << 24) || t.ny > (1 << 24) || t.nz > (1 << 24) || s.nx > (1 << 24) || s.ny > (1 << 24) ||
+        s.nz > (1 << 24))
+        throw Error(-1, "affine kernel: extent exceeds float32-exact index range");
+    AffineArgs a;
+    for (int i = 0; i < 12; ++i) a.m[i] = m.m[i];
+    a.tx = (int)t.nx; a.ty = (int)t.ny; a.tz = (int)t.nz;
+    a.sx = (int)s.nx; a.sy = (int)s.ny; a.sz = (int)s.nz;
+    return a;
+}
+
+}  // namespace
+
+void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s) {
+    AffineArgs a = make_args(out_dims, src_dims, m);
+    dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, a.tz);
+    if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "affine_resample: volume exceeds launch limits");
+    hipLaunchKernelGGL(resample_kernel, grid, dim3(kBlockThreads), 0, s, out, src, a);
+    MIL_HIP(hipGetLastError());
+}
+
+CorrWorkspace::CorrWorkspace() { MIL_HIP(hipHostMalloc((void **)&host, 2 * sizeof(double), hipHostMallocDefault)); }
+CorrWorkspace::~CorrWorkspace() {
+    if (host) (void)hipHostFree(host);
+}
+
+void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
+                     CorrWorkspace &ws, hipStream_t s) {
+    AffineArgs a = make_args(t_dims, s_dims, m);
+    dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
+    if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
+    if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
+    double *dev_out = ws.partials.get() + 2 * nblocks;
+    hipLaunchKernelGGL(corr_kernel, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(), (int)nblocks);
+    MIL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(kFinalThreads), 0, s, ws.partials.get(), (int)nblocks, dev_out);
+    MIL_HIP(hipGetLastError());
+    MIL_HIP(hipMemcpyAsync(ws.host, dev_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+}
+
+void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
+                    CorrWorkspace &ws, hipStream_t s, double *ss, double *st) {
+    corr_sums_async(target, src, t_dims, s_dims, m, ws, s);
+    MIL_HIP(hipStreamSynchronize(s));
+    *ss = ws.host[0];
+    *st = ws.host[1];
+}
+
+}  // namespace k
+}  // namespace mil

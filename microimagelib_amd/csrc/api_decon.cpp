@@ -1,0 +1,226 @@
+// libapi.h deconvolution entry points: host pointers in, host pointers out.
+// Mirrors the argument meaning, return codes and records[] layout of the reference's
+// decon_singleview / decon_dualview (src/api_decon.cpp:53-331, 333-704).
+#include <chrono>
+#include <cstdarg>
+#include <cstring>
+#include <memory>
+
+#include "../../include/libapi.h"
+#include "decon.h"
+
+using namespace mil;
+
+namespace {
+
+float free_mb() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0.f;
+    return (float)free_b / 1048576.0f;
+}
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Geometry {
+    Dims im, psf, box;
+    size_t n_im, n_psf, n_box, n_spec;
+    bool padded;
+};
+
+Geometry make_geometry(const unsigned int *imSize, const unsigned int *psfSize) {
+    Geometry g;
+    g.im = Dims{(long long)imSize[0], (long long)imSize[1], (long long)imSize[2]};
+    g.psf = Dims{(long long)psfSize[0], (long long)psfSize[1], (long long)psfSize[2]};
+    if (g.im.count() <= 0 || g.psf.count() <= 0) throw Error(-1, "decon: empty image or PSF");
+    // FFT box = snapTransformSize of each image extent (reference src/api_decon.cpp:77-79)
+    g.box = Dims{snap_transform_size((int)g.im.nx), snap_transform_size((int)g.im.ny),
+                 snap_transform_size((int)g.im.nz)};
+    g.n_im = (size_t)g.im.count();
+    g.n_psf = (size_t)g.psf.count();
+    g.n_box = (size_t)g.box.count();
+    g.n_spec = (size_t)(g.box.nx / 2 + 1) * g.box.ny * g.box.nz;
+    g.padded = g.box != g.im;
+    return g;
+}
+
+// Resolve the requested memory mode.  288 GB of HBM: the reference's memory-saving mode 2 is run
+// as mode 1; the CPU mode 0 is not part of this build.  Returns the mode used, or -1.
+int resolve_mode(int requested, size_t bytes_needed, bool verbose) {
+    if (requested == 1 || requested == 2) return 1;
+    if (requested == -1) {
+        size_t free_b = 0, total_b = 0;
+        MIL_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (free_b > bytes_needed) {
+            if (verbose) printf("\t... GPU memory is sufficient, processing in efficient mode !!!\n");
+            return 1;
+        }
+        fprintf(stderr, "[microimagelib_amd] decon: %.0f MB needed, %.0f MB free on the device\n",
+                bytes_needed / 1048576.0, free_b / 1048576.0);
+        return -1;
+    }
+    return -1;
+}
+
+void upload_volume(float *d_dst, float *d_stage, const float *h_src, const Geometry &g, hipStream_t s) {
+    if (g.padded) {  // reference src/api_decon.cpp:225-231
+        MIL_HIP(hipMemcpyAsync(d_stage, h_src, g.n_im * sizeof(float), hipMemcpyHostToDevice, s));
+        k::pad_stack(d_dst, d_stage, g.box, g.im, s);
+    } else {
+        MIL_HIP(hipMemcpyAsync(d_dst, h_src, g.n_im * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+}
+
+void download_volume(float *h_dst, float *d_src, float *d_stage, const Geometry &g, hipStream_t s) {
+    if (g.padded) {  // reference src/api_decon.cpp:237-243
+        k::crop_stack(d_stage, d_src, g.im, g.box, s);
+        MIL_HIP(hipMemcpyAsync(h_dst, d_stage, g.n_im * sizeof(float), hipMemcpyDeviceToHost, s));
+    } else {
+        MIL_HIP(hipMemcpyAsync(h_dst, d_src, g.n_im * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    MIL_HIP(hipStreamSynchronize(s));
+}
+
+// OTF + back-projector OTF for one view (reference src/api_decon.cpp:211-223).
+void make_otfs(DeconEngine &eng, float2 *d_otf, float2 *d_otf_bp, float *d_psf_stage, const float *h_psf,
+               const float *h_psf_bp, bool unmatch, const Geometry &g) {
+    hipStream_t s = eng.stream();
+    MIL_HIP(hipMemcpyAsync(d_psf_stage, h_psf, g.n_psf * sizeof(float), hipMemcpyHostToDevice, s));
+    eng.gen_otf(d_otf, d_psf_stage, g.psf, false);
+    if (unmatch) {
+        MIL_HIP(hipMemcpyAsync(d_psf_stage, h_psf_bp, g.n_psf * sizeof(float), hipMemcpyHostToDevice, s));
+        eng.gen_otf(d_otf_bp, d_psf_stage, g.psf, false);
+    } else {
+        eng.gen_otf(d_otf_bp, d_psf_stage, g.psf, true);  // matched back projector = flipped PSF
+    }
+}
+
+}  // namespace
+
+extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSize, float *h_psf,
+                                unsigned int *psfSize, bool flagConstInitial, int itNumForDecon, int deviceNum,
+                                int gpuMemMode, bool verbose, float *deconRecords, bool flagUnmatch,
+                                float *h_psf_bp) {
+    if (gpuMemMode == 0) {
+        printf("\n****CPU deconvolution (gpuMemMode 0) is not provided by the MI355X build ****\n");
+        return 1;
+    }
+    if (gpuMemMode < -1 || gpuMemMode > 2) {
+        printf("\n****Wrong gpuMemMode setup, no deconvolution performed !!! ****\n");
+        return 1;  // reference src/api_decon.cpp:316-318
+    }
+    return guarded("decon_singleview", [&]() -> int {
+        const double t_start = now_s();
+        MIL_HIP(hipSetDevice(deviceNum));
+        const Geometry g = make_geometry(imSize, psfSize);
+        if (verbose) {
+            printf("Image information:\n");
+            printf("...Image size %lld x %lld x %lld\n", g.im.nx, g.im.ny, g.im.nz);
+            printf("...PSF size %lld x %lld x %lld\n", g.psf.nx, g.psf.ny, g.psf.nz);
+            printf("...FFT size %lld x %lld x %lld\n", g.box.nx, g.box.ny, g.box.nz);
+        }
+        deconRecords[1] = free_mb();
+        // A, E, T (real) + OTF, OTF_bp, S (spectra) + PSF staging + FFT work area (~1 spectrum)
+        const size_t need = (3 * g.n_box + g.n_psf + (g.padded ? g.n_im : 0)) * sizeof(float) +
+                            4 * g.n_spec * sizeof(float2);
+        const int mode = resolve_mode(gpuMemMode, need, verbose);
+        if (mode < 0) return 1;
+        deconRecords[0] = (float)mode;
+        const double t_init = now_s();
+
+        DeconEngine eng(g.box, nullptr);
+        hipStream_t s = eng.stream();
+        DeviceBuffer<float> dA(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
+        DeviceBuffer<float2> dOtf(g.n_spec), dOtfBp(g.n_spec);
+        deconRecords[2] = free_mb();
+
+        make_otfs(eng, dOtf, dOtfBp, dPsf, h_psf, h_psf_bp, flagUnmatch, g);
+        upload_volume(dA, dStage, h_img, g, s);
+        eng.init_single(dA, dE, flagConstInitial);
+        const double t_loop = now_s();
+        eng.run_single(dE, dA, dOtf, dOtfBp, itNumForDecon);
+        eng.synchronize();
+        const double t_done = now_s();
+        if (verbose) printf("...Time cost for decon is %2.3f s\n", t_done - t_loop);
+        deconRecords[3] = free_mb();
+        download_volume(h_decon, dE, dStage, g, s);
+        deconRecords[4] = free_mb();
+        const double t_end = now_s();
+        deconRecords[5] = deconRecords[4];
+        deconRecords[6] = (float)(t_init - t_start);
+        deconRecords[7] = (float)(t_loop - t_init);
+        deconRecords[8] = (float)(t_done - t_loop);
+        deconRecords[9] = (float)(t_end - t_start);
+        return 0;
+    });
+}
+
+extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsigned int *imSize, float *h_psf1,
+                              float *h_psf2, unsigned int *psfSize, bool flagConstInitial, int itNumForDecon,
+                              int deviceNum, int gpuMemMode, bool verbose, float *deconRecords, bool flagUnmatch,
+                              float *h_psf_bp1, float *h_psf_bp2) {
+    if (gpuMemMode == 0) {
+        printf("\n****CPU deconvolution (gpuMemMode 0) is not provided by the MI355X build ****\n");
+        return -1;
+    }
+    if (gpuMemMode < -1 || gpuMemMode > 2) {
+        printf("\n****Wrong gpuMemMode setup, no deconvolution performed !!! ****\n");
+        return -1;  // reference src/api_decon.cpp:685-687
+    }
+    return guarded("decon_dualview", [&]() -> int {
+        const double t_start = now_s();
+        MIL_HIP(hipSetDevice(deviceNum));
+        const Geometry g = make_geometry(imSize, psfSize);
+        if (verbose) {
+            printf("\tImage information:\n");
+            printf("\t... Image size %lld x %lld x %lld\n", g.im.nx, g.im.ny, g.im.nz);
+            printf("\t... PSF size %lld x %lld x %lld\n", g.psf.nx, g.psf.ny, g.psf.nz);
+            printf("\t... FFT size %lld x %lld x %lld\n", g.box.nx, g.box.ny, g.box.nz);
+        }
+        deconRecords[1] = free_mb();
+        const size_t need = (4 * g.n_box + g.n_psf + (g.padded ? g.n_im : 0)) * sizeof(float) +
+                            6 * g.n_spec * sizeof(float2);
+        const int mode = resolve_mode(gpuMemMode, need, verbose);
+        if (mode < 0) return -1;
+        deconRecords[0] = (float)mode;
+        const double t_init = now_s();
+
+        DeconEngine eng(g.box, nullptr);
+        hipStream_t s = eng.stream();
+        DeviceBuffer<float> dA(g.n_box), dB(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
+        DeviceBuffer<float2> dOtf1(g.n_spec), dOtf2(g.n_spec), dOtfBp1(g.n_spec), dOtfBp2(g.n_spec);
+        deconRecords[2] = free_mb();
+
+        make_otfs(eng, dOtf1, dOtfBp1, dPsf, h_psf1, h_psf_bp1, flagUnmatch, g);  // reference :522-534
+        make_otfs(eng, dOtf2, dOtfBp2, dPsf, h_psf2, h_psf_bp2, flagUnmatch, g);  // :535-547
+        upload_volume(dA, dStage, h_img1, g, s);
+        if (g.padded) MIL_HIP(hipStreamSynchronize(s));  // dStage is reused for the second view
+        upload_volume(dB, dStage, h_img2, g, s);
+        eng.init_dual(dA, dB, dE, flagConstInitial);
+        const double t_loop = now_s();
+        eng.run_dual(dE, dA, dB, dOtf1, dOtf2, dOtfBp1, dOtfBp2, itNumForDecon);
+        eng.synchronize();
+        const double t_done = now_s();
+        deconRecords[3] = free_mb();
+        download_volume(h_decon, dE, dStage, g, s);
+        deconRecords[4] = free_mb();
+        const double t_end = now_s();
+        deconRecords[5] = deconRecords[4];
+        deconRecords[6] = (float)(t_init - t_start);
+        deconRecords[7] = (float)(t_loop - t_init);
+        deconRecords[8] = (float)(t_done - t_loop);
+        deconRecords[9] = (float)(t_end - t_start);
+        if (verbose) printf("\t... deconvolution done !!! \n");
+        return 0;
+    });
+}
+
+// Dead upstream (its guard at src/api_decon.cpp:1133 is always true, so it always returns 1
+// before doing any work); kept so the symbol resolves.
+extern "C" int fusion_dualview(float *, float *, float *, float *, float *, float *, float *, unsigned int *,
+                               unsigned int *, float *, float *, int, bool, int, float, int, float *, float *,
+                               unsigned int *, int, int, int, bool, float *, bool, float *, float *) {
+    printf("\n****Wrong gpuMemMode setup, processing stopped !!! ****\n");
+    return 1;
+}

@@ -1,0 +1,132 @@
+// libapi.h registration / affine-transform entry points (host pointers).
+// Mirrors reg3d, reg_3dgpu, atrans3dgpu, checkmatrix of the reference
+// (src/api_reg.cpp:58-84, 247-262, 264-652).
+#include <chrono>
+#include <cstring>
+
+#include "../../include/libapi.h"
+#include "reg.h"
+
+using namespace mil;
+
+namespace {
+
+float free_mb() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0.f;
+    return (float)free_b / 1048576.0f;
+}
+
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    StreamGuard() { MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~StreamGuard() {
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+}  // namespace
+
+extern "C" bool checkmatrix(float *iTmx, long long int sx, long long int sy, long long int sz) {
+    return check_matrix(iTmx, sx, sy, sz);
+}
+
+extern "C" int atrans3dgpu(float *h_reg, float *iTmx, float *h_img2, unsigned int *imSize1, unsigned int *imSize2,
+                           int deviceNum) {
+    return guarded("atrans3dgpu", [&]() -> int {
+        MIL_HIP(hipSetDevice(deviceNum));
+        const Dims out{(long long)imSize1[0], (long long)imSize1[1], (long long)imSize1[2]};
+        const Dims in{(long long)imSize2[0], (long long)imSize2[1], (long long)imSize2[2]};
+        StreamGuard sg;
+        DeviceBuffer<float> d_out((size_t)out.count()), d_in((size_t)in.count());
+        MIL_HIP(hipMemcpyAsync(d_in.get(), h_img2, (size_t)in.count() * sizeof(float), hipMemcpyHostToDevice, sg.s));
+        k::Affine12 m;
+        std::memcpy(m.m, iTmx, sizeof m.m);
+        k::affine_resample(d_out.get(), d_in.get(), out, in, m, sg.s);
+        MIL_HIP(hipMemcpyAsync(h_reg, d_out.get(), (size_t)out.count() * sizeof(float), hipMemcpyDeviceToHost, sg.s));
+        MIL_HIP(hipStreamSynchronize(sg.s));
+        return 0;
+    });
+}
+
+extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1,
+                     unsigned int *imSize2, int regChoice, int affMethod, bool flagTmx, float FTOL, int itLimit,
+                     int deviceNum, int gpuMemMode, bool verbose, float *records) {
+    if (gpuMemMode == 0) {  // same answer as the reference, src/api_reg.cpp:390-393
+        printf("\n ****CPU registraion function is under developing **** \n");
+        return -1;
+    }
+    if (gpuMemMode < -1 || gpuMemMode > 2) {
+        printf("\n****Wrong gpuMemMode setup, no deconvolution performed !!! ****\n");
+        return 1;  // :591-593
+    }
+    if (regChoice < 0 || regChoice > 4) {
+        printf("\n*** Wrong registration choice is setup, no registraiton performed !!! **** \n");
+        return 1;  // :512-514
+    }
+    if (regChoice == 1 || regChoice == 3 || regChoice == 4) {
+        // phasor / 2-D MIP pre-registration: "next" rows of the scope table, not built yet.
+        printf("\n ****regChoice %d (phasor / 2D-MIP pre-registration) is not provided by this build **** \n",
+               regChoice);
+        return -1;
+    }
+    return guarded("reg3d", [&]() -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        MIL_HIP(hipSetDevice(deviceNum));
+        records[8] = free_mb();
+        if (verbose) printf("\t... GPU free memory before registration is %.0f MB\n", records[8]);
+        const Dims d1{(long long)imSize1[0], (long long)imSize1[1], (long long)imSize1[2]};
+        const Dims d2{(long long)imSize2[0], (long long)imSize2[1], (long long)imSize2[2]};
+        const size_t n1 = (size_t)d1.count(), n2 = (size_t)d2.count();
+        records[0] = 1.f;  // modes 1, 2 and auto all run fully resident (288 GB HBM)
+
+        StreamGuard sg;
+        DeviceBuffer<float> d_t(n1), d_s(n1), d_reg(n1);
+        if (d1 == d2) {
+            MIL_HIP(hipMemcpyAsync(d_s.get(), h_img2, n2 * sizeof(float), hipMemcpyHostToDevice, sg.s));
+        } else {  // centred crop / zero-pad of the source to the target box (:401-406)
+            DeviceBuffer<float> raw(n2);
+            MIL_HIP(hipMemcpyAsync(raw.get(), h_img2, n2 * sizeof(float), hipMemcpyHostToDevice, sg.s));
+            k::align_size(d_s.get(), raw.get(), d1, d2, sg.s);
+            MIL_HIP(hipStreamSynchronize(sg.s));
+        }
+        MIL_HIP(hipMemcpyAsync(d_t.get(), h_img1, n1 * sizeof(float), hipMemcpyHostToDevice, sg.s));
+        records[9] = free_mb();
+        const int method = (regChoice == 0) ? 0 : affMethod;  // :412
+        reg3d_affine_device(d_reg.get(), iTmx, d_t.get(), d_s.get(), d1, method, flagTmx, FTOL, itLimit, verbose,
+                            records, sg.s);
+        MIL_HIP(hipMemcpyAsync(h_reg, d_reg.get(), n1 * sizeof(float), hipMemcpyDeviceToHost, sg.s));
+        MIL_HIP(hipStreamSynchronize(sg.s));
+        records[10] = free_mb();
+        records[7] = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (verbose) printf("\t... registration done !!! \n");
+        return 0;
+    });
+}
+
+extern "C" int reg_3dgpu(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1,
+                         unsigned int *imSize2, int affMethod, int inputTmx, float FTOL, int itLimit,
+                         int /*subBgTrigger*/, int deviceNum, float *regRecords) {
+    // reference src/api_reg.cpp:609-652: 2-D MIP pre-registration unless an input matrix is given,
+    // then a retry with plain affine registration when the matrix fails the sanity check.
+    int regChoice = 4;
+    bool flagTmx = false;
+    if (inputTmx == 1) {
+        flagTmx = true;
+        regChoice = 2;
+    }
+    int status = reg3d(h_reg, iTmx, h_img1, h_img2, imSize1, imSize2, regChoice, affMethod, flagTmx, FTOL, itLimit,
+                       deviceNum, 1, false, regRecords);
+    const bool ok = (status == 0) && checkmatrix(iTmx, imSize1[0], imSize1[1], imSize1[2]);
+    if (!ok) {
+        status = reg3d(h_reg, iTmx, h_img1, h_img2, imSize1, imSize2, 2, affMethod, flagTmx, FTOL, itLimit, deviceNum,
+                       1, false, regRecords);
+    }
+    return status;
+}
+
+extern "C" int reg2d(float *, float *, float *, float *, unsigned int *, unsigned int *, int, bool, float, int, int,
+                     int, bool, float *) {
+    printf("\n ****reg2d (2-D registration) is outside the hot path and not provided by this build **** \n");
+    return -1;
+}

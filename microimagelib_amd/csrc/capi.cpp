@@ -1,0 +1,216 @@
+// mil_device.h -- the thin device-pointer C ABI.  No C++ types cross this boundary.
+#include "../../include/mil_device.h"
+
+#include <cstring>
+
+#include "decon.h"
+#include "powell.h"
+#include "reg.h"
+
+using namespace mil;
+
+struct mil_decon {
+    DeconEngine engine;
+    mil_decon(Dims box, hipStream_t s) : engine(box, s) {}
+};
+
+namespace {
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline Dims dims3(int x, int y, int z) { return Dims{x, y, z}; }
+}  // namespace
+
+extern "C" {
+
+const char *mil_version(void) { return "microimagelib_amd 0.1 (gfx950)"; }
+
+int mil_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int mil_set_device(int device) {
+    return guarded("mil_set_device", [&] { MIL_HIP(hipSetDevice(device)); return 0; });
+}
+
+int mil_snap_transform_size(int n) { return snap_transform_size(n); }
+
+int mil_rl_ratio(float *d_T, const float *d_A, size_t n, void *stream) {
+    return guarded("mil_rl_ratio", [&] { k::rl_ratio(d_T, d_A, n, as_stream(stream)); return 0; });
+}
+int mil_rl_update(float *d_E, const float *d_T, size_t n, float eps, void *stream) {
+    return guarded("mil_rl_update", [&] { k::rl_update(d_E, d_T, n, eps, as_stream(stream)); return 0; });
+}
+int mil_cmul(void *d_S, const void *d_OTF, size_t n_complex, void *stream) {
+    return guarded("mil_cmul", [&] {
+        k::cmul_inplace((float2 *)d_S, (const float2 *)d_OTF, n_complex, as_stream(stream));
+        return 0;
+    });
+}
+int mil_sum_f64(const float *d_in, size_t n, double *h_out, void *stream) {
+    return guarded("mil_sum_f64", [&] {
+        k::ReduceWorkspace ws;
+        *h_out = k::reduce_sync(k::kSum, d_in, n, 0.f, ws, as_stream(stream));
+        return 0;
+    });
+}
+
+int mil_pad_psf(float *d_out, const float *d_psf, int fx, int fy, int fz, int px, int py, int pz, float scale, int flip,
+                void *stream) {
+    return guarded("mil_pad_psf", [&] {
+        k::pad_psf(d_out, d_psf, dims3(fx, fy, fz), dims3(px, py, pz), scale, flip != 0, as_stream(stream));
+        return 0;
+    });
+}
+int mil_pad_stack(float *d_out, const float *d_in, int fx, int fy, int fz, int sx, int sy, int sz, void *stream) {
+    return guarded("mil_pad_stack", [&] {
+        k::pad_stack(d_out, d_in, dims3(fx, fy, fz), dims3(sx, sy, sz), as_stream(stream));
+        return 0;
+    });
+}
+int mil_crop_stack(float *d_out, const float *d_in, int sx, int sy, int sz, int fx, int fy, int fz, void *stream) {
+    return guarded("mil_crop_stack", [&] {
+        k::crop_stack(d_out, d_in, dims3(sx, sy, sz), dims3(fx, fy, fz), as_stream(stream));
+        return 0;
+    });
+}
+int mil_align_size(float *d_out, const float *d_in, int ox, int oy, int oz, int ix, int iy, int iz, void *stream) {
+    return guarded("mil_align_size", [&] {
+        k::align_size(d_out, d_in, dims3(ox, oy, oz), dims3(ix, iy, iz), as_stream(stream));
+        return 0;
+    });
+}
+int mil_flip3(float *d_out, const float *d_in, int nx, int ny, int nz, void *stream) {
+    return guarded("mil_flip3", [&] { k::flip3(d_out, d_in, dims3(nx, ny, nz), as_stream(stream)); return 0; });
+}
+int mil_rot_y90(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream) {
+    return guarded("mil_rot_y90", [&] {
+        k::rot_y90(d_out, d_in, dims3(nx, ny, nz), direction, as_stream(stream));
+        return 0;
+    });
+}
+int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream) {
+    return guarded("mil_max_projection", [&] {
+        k::max_projection(d_out, d_in, dims3(nx, ny, nz), direction, as_stream(stream));
+        return 0;
+    });
+}
+
+int mil_decon_create(mil_decon **out, int nx, int ny, int nz, void *stream) {
+    *out = nullptr;
+    return guarded("mil_decon_create", [&] {
+        *out = new mil_decon(dims3(nx, ny, nz), as_stream(stream));
+        return 0;
+    });
+}
+void mil_decon_destroy(mil_decon *e) { delete e; }
+size_t mil_decon_real_count(const mil_decon *e) { return e->engine.real_count(); }
+size_t mil_decon_spectrum_count(const mil_decon *e) { return e->engine.spectrum_count(); }
+
+int mil_decon_gen_otf(mil_decon *e, void *d_otf, const float *d_psf, int px, int py, int pz, int flip) {
+    return guarded("mil_decon_gen_otf", [&] {
+        e->engine.gen_otf((float2 *)d_otf, d_psf, dims3(px, py, pz), flip != 0);
+        return 0;
+    });
+}
+int mil_decon_init_single(mil_decon *e, float *d_A, float *d_E, int const_init) {
+    return guarded("mil_decon_init_single", [&] { e->engine.init_single(d_A, d_E, const_init != 0); return 0; });
+}
+int mil_decon_init_dual(mil_decon *e, float *d_A, float *d_B, float *d_E, int const_init) {
+    return guarded("mil_decon_init_dual", [&] { e->engine.init_dual(d_A, d_B, d_E, const_init != 0); return 0; });
+}
+int mil_decon_run_single(mil_decon *e, float *d_E, const float *d_A, const void *d_otf, const void *d_otf_bp,
+                         int iters) {
+    return guarded("mil_decon_run_single", [&] {
+        e->engine.run_single(d_E, d_A, (const float2 *)d_otf, (const float2 *)d_otf_bp, iters);
+        return 0;
+    });
+}
+int mil_decon_run_dual(mil_decon *e, float *d_E, const float *d_A, const float *d_B, const void *d_otf1,
+                       const void *d_otf2, const void *d_otf_bp1, const void *d_otf_bp2, int iters) {
+    return guarded("mil_decon_run_dual", [&] {
+        e->engine.run_dual(d_E, d_A, d_B, (const float2 *)d_otf1, (const float2 *)d_otf2, (const float2 *)d_otf_bp1,
+                           (const float2 *)d_otf_bp2, iters);
+        return 0;
+    });
+}
+int mil_decon_sync(mil_decon *e) {
+    return guarded("mil_decon_sync", [&] { e->engine.synchronize(); return 0; });
+}
+int mil_decon_timer_enable(mil_decon *e, int which, int enable) {
+    if (which < 0 || which >= DeconEngine::kTimedCount) return -1;
+    e->engine.timers[which].enabled = enable != 0;
+    e->engine.timers[which].reset();
+    return 0;
+}
+int mil_decon_timer_read(mil_decon *e, int which, double *total_ms, size_t *launches) {
+    if (which < 0 || which >= DeconEngine::kTimedCount) return -1;
+    return guarded("mil_decon_timer_read", [&] {
+        e->engine.synchronize();
+        *launches = e->engine.timers[which].collect(total_ms);
+        e->engine.timers[which].reset();
+        return 0;
+    });
+}
+
+int mil_affine_resample(float *d_out, const float *d_src, int ox, int oy, int oz, int sx, int sy, int sz,
+                        const float *m12, void *stream) {
+    return guarded("mil_affine_resample", [&] {
+        k::Affine12 m;
+        std::memcpy(m.m, m12, sizeof m.m);
+        k::affine_resample(d_out, d_src, dims3(ox, oy, oz), dims3(sx, sy, sz), m, as_stream(stream));
+        return 0;
+    });
+}
+int mil_corr_sums(const float *d_target, const float *d_src, int tx, int ty, int tz, int sx, int sy, int sz,
+                  const float *m12, double *h_out, void *stream) {
+    return guarded("mil_corr_sums", [&] {
+        k::Affine12 m;
+        std::memcpy(m.m, m12, sizeof m.m);
+        k::CorrWorkspace ws;
+        k::corr_sums_sync(d_target, d_src, dims3(tx, ty, tz), dims3(sx, sy, sz), m, ws, as_stream(stream), &h_out[0],
+                          &h_out[1]);
+        return 0;
+    });
+}
+int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
+                     int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records, void *stream) {
+    return guarded("mil_reg3d_affine", [&] {
+        hipStream_t s = as_stream(stream);
+        bool own = false;
+        if (!s) {
+            MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            own = true;
+        }
+        int rc;
+        try {
+            rc = reg3d_affine_device(d_reg, iTmx, d_img1, d_img2, dims3(nx, ny, nz), affMethod, flagTmx != 0, FTOL,
+                                     itLimit, verbose != 0, records, s);
+        } catch (...) {
+            if (own) (void)hipStreamDestroy(s);
+            throw;
+        }
+        if (own) (void)hipStreamDestroy(s);
+        return rc;
+    });
+}
+
+int mil_powell(float *p, float *xi, int ld, int n, float ftol, int *iter, float *fret, mil_cost_fn f, void *user,
+               int *totalIt, int itLimit) {
+    if (n < 1 || ld < n || !f || !totalIt) return -1;
+    return guarded("mil_powell", [&] {
+        CostFn cost = [&](const float *x) -> float { return f(x, user); };
+        PowellResult r = powell_minimize(p, xi, ld, n, ftol, cost, totalIt, itLimit);
+        if (iter) *iter = r.iterations;
+        if (fret) *fret = r.fret;
+        return 0;
+    });
+}
+void mil_p2matrix(float *m12, const float *p12) { p2matrix(m12, p12); }
+void mil_matrix2p(float *p12, const float *m12) { matrix2p(p12, m12); }
+void mil_dof9tomatrix(float *m12, const float *p9, int dofNum) { dof9tomatrix(m12, p9, dofNum); }
+void mil_matrixmultiply(float *m, const float *m1, const float *m2) { matrixmultiply(m, m1, m2); }
+void mil_rot2matrix(float *m12, float theta, long long sx, long long sy, long long sz, int rotAxis) {
+    rot2matrix(m12, theta, sx, sy, sz, rotAxis);
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// Device-resident Richardson-Lucy engine (single- and dual-view) for MI355X.
+//
+// One engine = one FFT box on one GPU: rocFFT real 3-D plans created once, the work
+// buffer, the scratch volume T and the scratch half-spectrum S allocated once, one HIP
+// stream.  The RL loop enqueues 8 operations per view update and never synchronises
+// with the host (the reference issues cudaThreadSynchronize after every kernel,
+// src/api_subfunc.cu:248 etc.).
+#pragma once
+
+#include <rocfft/rocfft.h>
+
+#include <vector>
+
+#include "kernels.h"
+
+namespace mil {
+
+// snapTransformSize, reference src/api_subfunc.cu:57-87.
+int snap_transform_size(int n);
+
+class Fft3D {
+public:
+    Fft3D(Dims box, hipStream_t stream);
+    ~Fft3D();
+    Fft3D(const Fft3D &) = delete;
+    Fft3D &operator=(const Fft3D &) = delete;
+    void r2c(float *in, float2 *out);  // unnormalised, out-of-place
+    void c2r(float2 *in, float *out);  // unnormalised, out-of-place (may clobber `in`)
+    size_t work_bytes() const { return work_.size(); }
+
+private:
+    rocfft_plan fwd_ = nullptr, inv_ = nullptr;
+    rocfft_execution_info info_ = nullptr;
+    DeviceBuffer<char> work_;
+};
+
+struct KernelTimer {  // HIP-event bracket around one kernel family, on the engine's stream
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    size_t used = 0;
+    void begin(hipStream_t s);
+    void end(hipStream_t s);
+    // sums elapsed over recorded pairs; stream must be idle. Returns count.
+    size_t collect(double *total_ms);
+    void reset() { used = 0; }
+    ~KernelTimer();
+};
+
+class DeconEngine {
+public:
+    enum Timed { kTimeUpdate = 0, kTimeRatio = 1, kTimeCmul = 2, kTimeFft = 3, kTimedCount = 4 };
+
+    DeconEngine(Dims fft_box, hipStream_t stream /* nullptr: engine-owned stream */);
+    ~DeconEngine();
+    DeconEngine(const DeconEngine &) = delete;
+    DeconEngine &operator=(const DeconEngine &) = delete;
+
+    Dims box() const { return box_; }
+    size_t real_count() const { return (size_t)box_.count(); }
+    size_t spectrum_count() const { return (size_t)(box_.nx / 2 + 1) * box_.ny * box_.nz; }
+    hipStream_t stream() const { return stream_; }
+
+    // genOTFgpu (+ flipgpu when `flip`), reference src/api_subfunc.cu:3269-3307.
+    void gen_otf(float2 *d_otf, const float *d_psf, Dims psf_dims, bool flip, bool normalise = true);
+    // estimate initialisation, reference :3380-3388 / :3606-3618.  A (and B) are clamped in place.
+    void init_single(float *A, float *E, bool const_init);
+    void init_dual(float *A, float *B, float *E, bool const_init);
+    // one view update, reference :3406-3415.
+    void view_update(float *E, const float *M, const float2 *otf, const float2 *otf_bp);
+    void run_single(float *E, const float *A, const float2 *otf, const float2 *otf_bp, int iters);
+    void run_dual(float *E, const float *A, const float *B, const float2 *otf1, const float2 *otf2,
+                  const float2 *otf_bp1, const float2 *otf_bp2, int iters);
+    void synchronize();
+
+    KernelTimer timers[kTimedCount];
+    float *scratch_real() { return T_.get(); }
+
+private:
+    Dims box_;
+    hipStream_t stream_ = nullptr;
+    bool own_stream_ = false;
+    Fft3D *fft_ = nullptr;
+    DeviceBuffer<float> T_;
+    DeviceBuffer<float2> S_;
+    k::ReduceWorkspace red_;
+};
+
+}  // namespace mil

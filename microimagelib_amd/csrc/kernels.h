@@ -1,0 +1,75 @@
+// Internal C++ launch interface of the hand-written gfx950 kernels.
+// Every launcher enqueues on `s` and returns without synchronising (except the
+// *_sync reductions, which hand a scalar back to the host).
+#pragma once
+
+#include "mil_common.h"
+
+namespace mil {
+namespace k {
+
+// ---- RL element-wise (kernels.hip) -----------------------------------------
+void rl_ratio(float *T, const float *A, size_t n, hipStream_t s);              // T = A / T
+void rl_update(float *E, const float *T, size_t n, float eps, hipStream_t s);   // E = max(E*T, eps)
+void cmul_inplace(float2 *S, const float2 *OTF, size_t n, hipStream_t s);      // S *= OTF (complex)
+void clamp_min(float *out, const float *in, size_t n, float eps, hipStream_t s);
+void init_single(float *A, float *E, size_t n, float eps, hipStream_t s);       // A=max(A,eps); E=A
+void init_dual(float *A, float *B, float *E, size_t n, float eps, hipStream_t s);
+void fill(float *out, float v, size_t n, hipStream_t s);
+void scale(float *out, const float *in, float c, size_t n, hipStream_t s);      // out = in * c
+void add_value(float *out, const float *in, float c, size_t n, hipStream_t s);  // out = in + c
+
+// ---- reductions (float64 accumulation, deterministic two-stage) ------------
+enum ReduceOp { kSum = 0, kSumSqShifted = 1 };
+struct ReduceWorkspace {
+    DeviceBuffer<double> partials;  // kMaxReduceBlocks * 2
+    double *host = nullptr;         // pinned, 2 doubles
+    ReduceWorkspace();
+    ~ReduceWorkspace();
+    ReduceWorkspace(const ReduceWorkspace &) = delete;
+    ReduceWorkspace &operator=(const ReduceWorkspace &) = delete;
+};
+// sum(in) or sum((in+c)^2) with the square formed in float32 like the reference's
+// addvaluegpu -> multi3Dgpu -> sum3Dgpu chain.  Synchronises `s`.
+double reduce_sync(ReduceOp op, const float *in, size_t n, float c, ReduceWorkspace &ws, hipStream_t s);
+
+// ---- geometry (all x-fastest, output-driven, coalesced) --------------------
+// out[(i - P/2) mod F] = scale * psf[flip ? P-1-i : i]; rest of the F box zero.  P <= F per axis.
+void pad_psf(float *out, const float *psf, Dims F, Dims P, float scale, bool flip, hipStream_t s);
+// centred placement with edge replication, offset (F - S)/2.
+void pad_stack(float *out, const float *in, Dims F, Dims S, hipStream_t s);
+// centred crop, offset (F - S)/2.
+void crop_stack(float *out, const float *in, Dims S, Dims F, hipStream_t s);
+// centred crop-or-zero-pad, offset trunc((O - I)/2).
+void align_size(float *out, const float *in, Dims O, Dims I, hipStream_t s);
+// out = in reversed on all three axes.
+void flip3(float *out, const float *in, Dims d, hipStream_t s);
+// 90-degree rotations about Y (rotbyyaxiskernel), direction +1 / -1; `in` dims given.
+void rot_y90(float *out, const float *in, Dims in_dims, int direction, hipStream_t s);
+// maximum-intensity projections with accumulator starting at 0 (maxprojectionkernel).
+void max_projection(float *out, const float *in, Dims d, int direction, hipStream_t s);
+
+// ---- affine (affine.hip) ---------------------------------------------------
+struct Affine12 {
+    float m[12];
+};
+// out[x,y,z] = trilinear(src, M*(x,y,z,1)) inside the window, 0 outside.
+void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m,
+                     hipStream_t s);
+struct CorrWorkspace {
+    DeviceBuffer<double> partials;  // 2 * kMaxCorrBlocks
+    double *host = nullptr;         // pinned: {sum s*s, sum s*t}
+    CorrWorkspace();
+    ~CorrWorkspace();
+    CorrWorkspace(const CorrWorkspace &) = delete;
+    CorrWorkspace &operator=(const CorrWorkspace &) = delete;
+};
+// Enqueue the fused interpolate + correlate + reduce; result lands in ws.host after
+// the stream is synchronised (corr_sums_sync does that and returns it).
+void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
+                     CorrWorkspace &ws, hipStream_t s);
+void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
+                    CorrWorkspace &ws, hipStream_t s, double *ss, double *st);
+
+}  // namespace k
+}  // namespace mil

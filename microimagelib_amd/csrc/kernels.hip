@@ -1,0 +1,540 @@
+// Hand-written gfx950 (CDNA4) kernels for the Richardson-Lucy hot path:
+// element-wise maps, float64 reductions and the pad / crop / flip family.
+//
+// All of these are HBM-bound (no contraction anywhere -> no MFMA).  Design rules
+// applied (cdna_hip_programming.md G2/G11/G13, Appendix B "Element-wise"):
+//   * 16 B per lane per access (float4), 64-lane waves fully coalesced: one wave
+//     instruction moves 1 KiB;
+//   * several independent loads in flight per lane before the first use;
+//   * grids of >> 256 workgroups so all 8 XCDs / 256 CUs stream;
+//   * x (TIFF fastest axis) is always the lane axis -- the reference's pad / crop /
+//     flip kernels put threadIdx.x on the slowest axis (include/cukernel.cuh:694,735,
+//     750,768) and are fully uncoalesced; these are not.
+// This file is compiled with -ffp-contract=off so every float op rounds exactly like
+// the reference's separate multiply / subtract kernels (bit-exact vs the oracle).
+#include "kernels.h"
+
+#include <cstdint>
+
+namespace mil {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kUnroll = 4;       // float4 per lane in flight
+constexpr int kMaxGrid = 16384;  // cap; grid-stride beyond
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int ew_grid(size_t n4) {
+    size_t per_block = (size_t)kBlock * kUnroll;
+    size_t g = (n4 + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > (size_t)kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+// ---- functors -------------------------------------------------------------
+struct RatioOp {  // div3Dkernel, reference include/cukernel.cuh:196-206 (unguarded divide)
+    __device__ __forceinline__ float operator()(float t, float a) const { return a / t; }
+};
+struct UpdateOp {  // multi3Dkernel :115-126 fused with maxvalue3Dgpukernel :383-392
+    float eps;
+    __device__ __forceinline__ float operator()(float e, float t) const {
+        float v = e * t;
+        return (v > eps) ? v : eps;
+    }
+};
+
+// io[i] = op(io[i], in[i]) -- 2 reads + 1 write per element.
+template <class Op>
+__global__ __launch_bounds__(kBlock) void ew_inplace2_kernel(float *__restrict__ io, const float *__restrict__ in,
+                                                           size_t n, Op op) {
+    const size_t n4 = n >> 2;
+    float4 *io4 = reinterpret_cast<float4 *>(io);
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    const size_t tile = (size_t)kBlock * kUnroll;
+    for (size_t base = (size_t)blockIdx.x * tile; base < n4; base += (size_t)gridDim.x * tile) {
+        float4 a[kUnroll], b[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            size_t i = base + threadIdx.x + (size_t)j * kBlock;
+            if (i < n4) {
+                a[j] = io4[i];
+                b[j] = in4[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            size_t i = base + threadIdx.x + (size_t)j * kBlock;
+            if (i < n4) {
+                float4 r;
+                r.x = op(a[j].x, b[j].x);
+                r.y = op(a[j].y, b[j].y);
+                r.z = op(a[j].z, b[j].z);
+                r.w = op(a[j].w, b[j].w);
+                io4[i] = r;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // ragged tail
+        size_t i = (n4 << 2) + threadIdx.x;
+        io[i] = op(io[i], in[i]);
+    }
+}
+
+template <class Op>
+__global__ __launch_bounds__(kBlock) void ew_inplace2_scalar_kernel(float *io, const float *in, size_t n, Op op) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        io[i] = op(io[i], in[i]);
+}
+
+template <class Op>
+void launch_inplace2(float *io, const float *in, size_t n, Op op, hipStream_t s) {
+    if (n == 0) return;
+    if (aligned16(io) && aligned16(in)) {
+        hipLaunchKernelGGL(ew_inplace2_kernel<Op>, dim3(ew_grid(n >> 2)), dim3(kBlock), 0, s, io, in, n, op);
+    } else {  // misaligned sub-buffer: scalar path, still coalesced
+        size_t g = (n + kBlock - 1) / kBlock;
+        if (g > (size_t)kMaxGrid) g = kMaxGrid;
+        hipLaunchKernelGGL(ew_inplace2_scalar_kernel<Op>, dim3((int)g), dim3(kBlock), 0, s, io, in, n, op);
+    }
+    MIL_HIP(hipGetLastError());
+}
+
+// Complex product in place: S[i] = S[i] * O[i]; float4 = two complex64 per lane.
+// multicomplex3Dkernel, reference include/cukernel.cuh:140-152.
+__global__ __launch_bounds__(kBlock) void cmul_kernel(float2 *__restrict__ S, const float2 *__restrict__ O, size_t n) {
+    const size_t n2 = n >> 1;
+    float4 *S4 = reinterpret_cast<float4 *>(S);
+    const float4 *O4 = reinterpret_cast<const float4 *>(O);
+    const size_t tile = (size_t)kBlock * kUnroll;
+    for (size_t base = (size_t)blockIdx.x * tile; base < n2; base += (size_t)gridDim.x * tile) {
+        float4 a[kUnroll], b[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            size_t i = base + threadIdx.x + (size_t)j * kBlock;
+            if (i < n2) {
+                a[j] = S4[i];
+                b[j] = O4[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            size_t i = base + threadIdx.x + (size_t)j * kBlock;
+            if (i < n2) {
+                float4 r;
+                r.x = a[j].x * b[j].x - a[j].y * b[j].y;
+                r.y = a[j].x * b[j].y + a[j].y * b[j].x;
+                r.z = a[j].z * b[j].z - a[j].w * b[j].w;
+                r.w = a[j].z * b[j].w + a[j].w * b[j].z;
+                S4[i] = r;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        float2 a = S[n - 1], b = O[n - 1];
+        S[n - 1] = make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cmul_scalar_kernel(float2 *S, const float2 *O, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        float2 a = S[i], b = O[i];
+        S[i] = make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    }
+}
+
+// Generic 1-input / up-to-2-output map used by the (cold) init kernels.
+enum MapKind { kClamp, kScale, kAddValue, kFill };
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void map_kernel(float *out, const float *in, size_t n, float c) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        float v = (KIND == kFill) ? c : in[i];
+        if (KIND == kClamp) v = (v > c) ? v : c;  // maxvalue3Dgpukernel
+        if (KIND == kScale) v = v * c;            // multivaluekernel
+        if (KIND == kAddValue) v = v + c;         // addvaluekernel
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void init_single_kernel(float *A, float *E, size_t n, float eps) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        float a = A[i];
+        a = (a > eps) ? a : eps;
+        A[i] = a;
+        E[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void init_dual_kernel(float *A, float *B, float *E, size_t n, float eps) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        float a = A[i], b = B[i];
+        a = (a > eps) ? a : eps;
+        b = (b > eps) ? b : eps;
+        A[i] = a;
+        B[i] = b;
+        E[i] = (a + b) * 0.5f;  // add3Dgpu then multivaluegpu(0.5), reference src/api_subfunc.cu:3616-3617
+    }
+}
+
+inline int flat_grid(size_t n) {
+    size_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return (int)g;
+}
+
+// ---- float64 reduction ------------------------------------------------------
+constexpr int kMaxReduceBlocks = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *lds /* >= kBlock/64 */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) r += lds[w];
+    }
+    __syncthreads();
+    return r;  // valid in thread 0
+}
+
+template <int OP>
+__device__ __forceinline__ double red_term(float x, float c) {
+    if (OP == kSum) return (double)x;
+    float v = x + c;  // addvaluegpu
+    float q = v * v;  // multi3Dgpu (float32 square)
+    return (double)q;
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void reduce_kernel(const float *__restrict__ in, size_t n, float c,
+                                                      double *__restrict__ partials, int vec_ok) {
+    __shared__ double lds[kBlock / 64];
+    double acc = 0.0;
+    const size_t n4 = vec_ok ? (n >> 2) : 0;
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+        float4 v = in4[i];
+        acc += red_term<OP>(v.x, c);
+        acc += red_term<OP>(v.y, c);
+        acc += red_term<OP>(v.z, c);
+        acc += red_term<OP>(v.w, c);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        acc += red_term<OP>(in[i], c);
+    double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// Fixed-order final pass: one workgroup, `count` partials per channel.
+__global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double *__restrict__ partials, int count,
+                                                            int channels, double *__restrict__ out) {
+    __shared__ double lds[kBlock / 64];
+    for (int ch = 0; ch < channels; ++ch) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < count; i += kBlock) acc += partials[(size_t)ch * count + i];
+        double r = block_sum(acc, lds);
+        if (threadIdx.x == 0) out[ch] = r;
+    }
+}
+
+// ---- geometry ---------------------------------------------------------------
+struct Geo {
+    int fx, fy, fz;  // output box
+    int sx, sy, sz;  // input box
+    int ox, oy, oz;  // offsets / origins
+};
+
+__device__ __forceinline__ bool out_xyz(const Geo &g, int &x, int &y, int &z) {
+    x = blockIdx.x * blockDim.x + threadIdx.x;
+    y = blockIdx.y;
+    z = blockIdx.z;
+    return x < g.fx;
+}
+
+// padPSFgpukernel (reference include/cukernel.cuh:680-697) turned inside out: for
+// every voxel d of the F box, the PSF sample that lands there is i = d + o (front part)
+// or i = d + o - F (wrapped part), o = P/2; nothing else does -> 0.
+__device__ __forceinline__ int psf_src(int d, int F, int P, int o) {
+    int i = d + o;
+    if (i < P) return i;  // d in [0, P - o)
+    i -= F;               // d in [F - o, F)
+    return (i >= 0 && i < o) ? i : -1;
+}
+
+__global__ void pad_psf_kernel(float *__restrict__ out, const float *__restrict__ psf, Geo g, float scale, int flip) {
+    int x, y, z;
+    if (!out_xyz(g, x, y, z)) return;
+    int ix = psf_src(x, g.fx, g.sx, g.ox);
+    int iy = psf_src(y, g.fy, g.sy, g.oy);
+    int iz = psf_src(z, g.fz, g.sz, g.oz);
+    float v = 0.0f;
+    if (ix >= 0 && iy >= 0 && iz >= 0) {
+        if (flip) {  // flipgpukernel :668-677 folded in
+            ix = g.sx - 1 - ix;
+            iy = g.sy - 1 - iy;
+            iz = g.sz - 1 - iz;
+        }
+        v = psf[(size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)] * scale;
+    }
+    out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] = v;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// padstackgpukernel :700-737 -- edge replication == clamped source index.
+__global__ void pad_stack_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g) {
+    int x, y, z;
+    if (!out_xyz(g, x, y, z)) return;
+    int ix = clampi(x - g.ox, 0, g.sx - 1);
+    int iy = clampi(y - g.oy, 0, g.sy - 1);
+    int iz = clampi(z - g.oz, 0, g.sz - 1);
+    out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] =
+        in[(size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)];
+}
+
+// cropgpukernel :740-753 (g.f* = cropped output box, g.s* = big input box).
+__global__ void crop_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g) {
+    int x, y, z;
+    if (!out_xyz(g, x, y, z)) return;
+    int ix = x + g.ox, iy = y + g.oy, iz = z + g.oz;
+    if (ix < g.sx && iy < g.sy && iz < g.sz)
+        out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] =
+            in[(size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)];
+}
+
+// alignsize3Dgpukernel :755-769.
+__global__ void align_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g) {
+    int x, y, z;
+    if (!out_xyz(g, x, y, z)) return;
+    int ix = x - g.ox, iy = y - g.oy, iz = z - g.oz;
+    float v = 0.0f;
+    if (ix >= 0 && iy >= 0 && iz >= 0 && ix < g.sx && iy < g.sy && iz < g.sz)
+        v = in[(size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)];
+    out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] = v;
+}
+
+__global__ void flip_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g) {
+    int x, y, z;
+    if (!out_xyz(g, x, y, z)) return;
+    out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] =
+        in[(size_t)(g.fx - 1 - x) + (size_t)g.fx * ((size_t)(g.fy - 1 - y) + (size_t)g.fy * (g.fz - 1 - z))];
+}
+
+// rotbyyaxiskernel :438-453.  Input dims (sx,sy,sz) x-fastest; output dims (sz,sy,sx).
+//  +1: out[(sx-1-i)*sy*sz + j*sz + k] = in[k*sy*sx + j*sx + i]
+//  -1: out[i*sy*sz + j*sz + (sz-1-k)] = in[k*sy*sx + j*sx + i]
+// Output-driven: output fastest index runs over the input's z.
+__global__ void rot_y90_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g, int direction) {
+    // g.f* = output dims (fx = in.sz, fy = in.sy, fz = in.sx); g.s* = input dims
+    int ox, oy, oz;
+    if (!out_xyz(g, ox, oy, oz)) return;
+    int i, k;
+    if (direction == 1) {
+        k = ox;
+        i = g.sx - 1 - oz;
+    } else {
+        k = g.sz - 1 - ox;
+        i = oz;
+    }
+    out[(size_t)ox + (size_t)g.fx * ((size_t)oy + (size_t)g.fy * oz)] =
+        in[(size_t)i + (size_t)g.sx * ((size_t)oy + (size_t)g.sy * k)];
+}
+
+// maxprojectionkernel :396-418 -- accumulator starts at 0 (negative data projects to 0).
+__global__ void max_projection_kernel(float *__restrict__ out, const float *__restrict__ in, int sx, int sy, int sz,
+                                      int psx, int psy, int psz, int dir) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= psx || j >= psy) return;
+    const size_t zs = (size_t)sx * sy;
+    float a = 0.0f;
+    if (dir == 1) {
+        for (int k = 0; k < psz; ++k) { float v = in[i + (size_t)sx * j + zs * k]; a = (a > v) ? a : v; }
+    } else if (dir == 2) {
+        for (int k = 0; k < psz; ++k) { float v = in[j + (size_t)sx * k + zs * i]; a = (a > v) ? a : v; }
+    } else {
+        for (int k = 0; k < psz; ++k) { float v = in[k + (size_t)sx * i + zs * j]; a = (a > v) ? a : v; }
+    }
+    out[i + (size_t)j * psx] = a;
+}
+
+inline void geo_launch_dims(const Geo &g, dim3 &grid, dim3 &block) {
+    int bx = g.fx >= 256 ? 256 : (g.fx > 64 ? 128 : 64);
+    block = dim3(bx, 1, 1);
+    grid = dim3((g.fx + bx - 1) / bx, g.fy, g.fz);
+}
+
+inline Geo make_geo(Dims F, Dims S) {
+    if (F.nx <= 0 || F.ny <= 0 || F.nz <= 0 || S.nx <= 0 || S.ny <= 0 || S.nz <= 0)
+        throw Error(-1, "geometry kernel: empty volume");
+    if (F.ny > 65535 || F.nz > 65535 || F.nx > (1LL << 30) || S.count() > (1LL << 40))
+        throw Error(-1, "geometry kernel: volume extent exceeds launch limits");
+    Geo g;
+    g.fx = (int)F.nx; g.fy = (int)F.ny; g.fz = (int)F.nz;
+    g.sx = (int)S.nx; g.sy = (int)S.ny; g.sz = (int)S.nz;
+    g.ox = g.oy = g.oz = 0;
+    return g;
+}
+
+inline int cdiv2(long long a) { return (int)(a / 2); }  // C truncation toward zero
+
+}  // namespace
+
+// ---- launchers --------------------------------------------------------------
+void rl_ratio(float *T, const float *A, size_t n, hipStream_t s) { launch_inplace2(T, A, n, RatioOp{}, s); }
+
+void rl_update(float *E, const float *T, size_t n, float eps, hipStream_t s) {
+    launch_inplace2(E, T, n, UpdateOp{eps}, s);
+}
+
+void cmul_inplace(float2 *S, const float2 *OTF, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    if (aligned16(S) && aligned16(OTF)) {
+        hipLaunchKernelGGL(cmul_kernel, dim3(ew_grid(n >> 1)), dim3(kBlock), 0, s, S, OTF, n);
+    } else {
+        hipLaunchKernelGGL(cmul_scalar_kernel, dim3(flat_grid(n)), dim3(kBlock), 0, s, S, OTF, n);
+    }
+    MIL_HIP(hipGetLastError());
+}
+
+void clamp_min(float *out, const float *in, size_t n, float eps, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(map_kernel<kClamp>, dim3(flat_grid(n)), dim3(kBlock), 0, s, out, in, n, eps);
+    MIL_HIP(hipGetLastError());
+}
+void scale(float *out, const float *in, float c, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(map_kernel<kScale>, dim3(flat_grid(n)), dim3(kBlock), 0, s, out, in, n, c);
+    MIL_HIP(hipGetLastError());
+}
+void add_value(float *out, const float *in, float c, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(map_kernel<kAddValue>, dim3(flat_grid(n)), dim3(kBlock), 0, s, out, in, n, c);
+    MIL_HIP(hipGetLastError());
+}
+void fill(float *out, float v, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(map_kernel<kFill>, dim3(flat_grid(n)), dim3(kBlock), 0, s, out, (const float *)nullptr, n, v);
+    MIL_HIP(hipGetLastError());
+}
+void init_single(float *A, float *E, size_t n, float eps, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(init_single_kernel, dim3(flat_grid(n)), dim3(kBlock), 0, s, A, E, n, eps);
+    MIL_HIP(hipGetLastError());
+}
+void init_dual(float *A, float *B, float *E, size_t n, float eps, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(init_dual_kernel, dim3(flat_grid(n)), dim3(kBlock), 0, s, A, B, E, n, eps);
+    MIL_HIP(hipGetLastError());
+}
+
+ReduceWorkspace::ReduceWorkspace() {
+    partials.alloc(2 * kMaxReduceBlocks + 2);
+    MIL_HIP(hipHostMalloc((void **)&host, 2 * sizeof(double), hipHostMallocDefault));
+}
+ReduceWorkspace::~ReduceWorkspace() {
+    if (host) (void)hipHostFree(host);
+}
+
+double reduce_sync(ReduceOp op, const float *in, size_t n, float c, ReduceWorkspace &ws, hipStream_t s) {
+    if (n == 0) return 0.0;
+    size_t want = (n / 4 + kBlock - 1) / kBlock;
+    int blocks = (int)(want < 1 ? 1 : (want > (size_t)kMaxReduceBlocks ? kMaxReduceBlocks : want));
+    int vec_ok = aligned16(in) ? 1 : 0;
+    double *out = ws.partials.get() + 2 * kMaxReduceBlocks;
+    if (op == kSum)
+        hipLaunchKernelGGL(reduce_kernel<kSum>, dim3(blocks), dim3(kBlock), 0, s, in, n, c, ws.partials.get(), vec_ok);
+    else
+        hipLaunchKernelGGL(reduce_kernel<kSumSqShifted>, dim3(blocks), dim3(kBlock), 0, s, in, n, c,
+                           ws.partials.get(), vec_ok);
+    MIL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws.partials.get(), blocks, 1, out);
+    MIL_HIP(hipGetLastError());
+    MIL_HIP(hipMemcpyAsync(ws.host, out, sizeof(double), hipMemcpyDeviceToHost, s));
+    MIL_HIP(hipStreamSynchronize(s));
+    return ws.host[0];
+}
+
+void pad_psf(float *out, const float *psf, Dims F, Dims P, float scale_v, bool flip, hipStream_t s) {
+    if (P.nx > F.nx || P.ny > F.ny || P.nz > F.nz) throw Error(-1, "pad_psf: PSF larger than FFT box");
+    Geo g = make_geo(F, P);
+    g.ox = (int)(P.nx / 2); g.oy = (int)(P.ny / 2); g.oz = (int)(P.nz / 2);  // reference src/api_subfunc.cu:1695
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(pad_psf_kernel, grid, block, 0, s, out, psf, g, scale_v, flip ? 1 : 0);
+    MIL_HIP(hipGetLastError());
+}
+
+void pad_stack(float *out, const float *in, Dims F, Dims S, hipStream_t s) {
+    if (S.nx > F.nx || S.ny > F.ny || S.nz > F.nz) throw Error(-1, "pad_stack: image larger than FFT box");
+    Geo g = make_geo(F, S);
+    g.ox = (int)((F.nx - S.nx) / 2); g.oy = (int)((F.ny - S.ny) / 2); g.oz = (int)((F.nz - S.nz) / 2);  // :1717-1719
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(pad_stack_kernel, grid, block, 0, s, out, in, g);
+    MIL_HIP(hipGetLastError());
+}
+
+void crop_stack(float *out, const float *in, Dims S, Dims F, hipStream_t s) {
+    if (S.nx > F.nx || S.ny > F.ny || S.nz > F.nz) throw Error(-1, "crop_stack: crop larger than input");
+    Geo g = make_geo(S, F);
+    g.ox = (int)((F.nx - S.nx) / 2); g.oy = (int)((F.ny - S.ny) / 2); g.oz = (int)((F.nz - S.nz) / 2);  // :1740-1742
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(crop_kernel, grid, block, 0, s, out, in, g);
+    MIL_HIP(hipGetLastError());
+}
+
+void align_size(float *out, const float *in, Dims O, Dims I, hipStream_t s) {
+    Geo g = make_geo(O, I);
+    g.ox = cdiv2(O.nx - I.nx); g.oy = cdiv2(O.ny - I.ny); g.oz = cdiv2(O.nz - I.nz);  // :1783-1785
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(align_kernel, grid, block, 0, s, out, in, g);
+    MIL_HIP(hipGetLastError());
+}
+
+void flip3(float *out, const float *in, Dims d, hipStream_t s) {
+    Geo g = make_geo(d, d);
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(flip_kernel, grid, block, 0, s, out, in, g);
+    MIL_HIP(hipGetLastError());
+}
+
+void rot_y90(float *out, const float *in, Dims in_dims, int direction, hipStream_t s) {
+    if (direction != 1 && direction != -1) throw Error(-1, "rot_y90: direction must be +1 or -1");
+    Dims od{in_dims.nz, in_dims.ny, in_dims.nx};
+    Geo g = make_geo(od, in_dims);
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(rot_y90_kernel, grid, block, 0, s, out, in, g, direction);
+    MIL_HIP(hipGetLastError());
+}
+
+void max_projection(float *out, const float *in, Dims d, int direction, hipStream_t s) {
+    int sx = (int)d.nx, sy = (int)d.ny, sz = (int)d.nz, psx, psy, psz;
+    if (direction == 1) { psx = sx; psy = sy; psz = sz; }       // reference src/api_subfunc.cu:492-501
+    else if (direction == 2) { psx = sz; psy = sx; psz = sy; }
+    else if (direction == 3) { psx = sy; psy = sz; psz = sx; }
+    else throw Error(-1, "max_projection: direction must be 1, 2 or 3");
+    int bx = psx >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(max_projection_kernel, dim3((psx + bx - 1) / bx, psy, 1), dim3(bx), 0, s, out, in, sx, sy, sz,
+                       psx, psy, psz, direction);
+    MIL_HIP(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace mil

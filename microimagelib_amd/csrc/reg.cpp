@@ -1,0 +1,269 @@
+#include "reg.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "powell.h"
+
+namespace mil {
+
+// ---------------------------------------------------------------------------
+// matrix parameterisations
+// ---------------------------------------------------------------------------
+void p2matrix(float *m, const float *p) {  // translations first, then the 3x3 block row by row
+    m[3] = p[0]; m[7] = p[1]; m[11] = p[2];
+    m[0] = p[3]; m[1] = p[4]; m[2] = p[5];
+    m[4] = p[6]; m[5] = p[7]; m[6] = p[8];
+    m[8] = p[9]; m[9] = p[10]; m[10] = p[11];
+}
+
+void matrix2p(float *p, const float *m) {
+    p[0] = m[3]; p[1] = m[7]; p[2] = m[11];
+    p[3] = m[0]; p[4] = m[1]; p[5] = m[2];
+    p[6] = m[4]; p[7] = m[5]; p[8] = m[6];
+    p[9] = m[8]; p[10] = m[9]; p[11] = m[10];
+}
+
+void matrixmultiply(float *m, const float *a, const float *b) {
+    float out[12];
+    for (int r = 0; r < 3; ++r) {
+        const float a0 = a[4 * r], a1 = a[4 * r + 1], a2 = a[4 * r + 2], a3 = a[4 * r + 3];
+        out[4 * r + 0] = a0 * b[0] + a1 * b[4] + a2 * b[8];
+        out[4 * r + 1] = a0 * b[1] + a1 * b[5] + a2 * b[9];
+        out[4 * r + 2] = a0 * b[2] + a1 * b[6] + a2 * b[10];
+        out[4 * r + 3] = a0 * b[3] + a1 * b[7] + a2 * b[11] + a3;
+    }
+    std::memcpy(m, out, sizeof out);
+}
+
+namespace {
+
+void set_identity(float *m) {
+    for (int i = 0; i < 12; ++i) m[i] = 0.f;
+    m[0] = m[5] = m[10] = 1.f;
+}
+
+}  // namespace
+
+void dof9tomatrix(float *m, const float *p, int dof_num) {
+    // p: x y z alpha beta theta a b c; only the first dof_num entries are read, the rest take
+    // their defaults (angles 0, scales 1).  M = [diag(a,b,c) | t] * Rz(alpha) * Rx(beta) * Ry(theta).
+    float x = p[0], y = p[1], z = p[2];
+    float alpha = 0.f, beta = 0.f, theta = 0.f, a = 1.f, b = 1.f, c = 1.f;
+    if (dof_num >= 6) {  // degrees / 57.3 evaluated in double, stored as float
+        alpha = (float)((double)p[3] / 57.3);
+        beta = (float)((double)p[4] / 57.3);
+        theta = (float)((double)p[5] / 57.3);
+    }
+    if (dof_num == 7) a = b = c = p[6];
+    if (dof_num == 9) { a = p[6]; b = p[7]; c = p[8]; }
+    float ts[12], rot[12], t1[12], t2[12];
+    set_identity(ts);
+    ts[0] = a; ts[5] = b; ts[10] = c;
+    ts[3] = x; ts[7] = y; ts[11] = z;
+    set_identity(rot);  // about Z
+    rot[0] = std::cos(alpha); rot[1] = std::sin(alpha);
+    rot[4] = -std::sin(alpha); rot[5] = std::cos(alpha);
+    matrixmultiply(t1, ts, rot);
+    set_identity(rot);  // about X
+    rot[5] = std::cos(beta); rot[6] = std::sin(beta);
+    rot[9] = -std::sin(beta); rot[10] = std::cos(beta);
+    matrixmultiply(t2, t1, rot);
+    set_identity(rot);  // about Y
+    rot[0] = std::cos(theta); rot[2] = -std::sin(theta);
+    rot[8] = std::sin(theta); rot[10] = std::cos(theta);
+    matrixmultiply(m, t2, rot);
+}
+
+void rot2matrix(float *m, float theta, long long sx, long long sy, long long sz, int rot_axis) {
+    // shift the rotated box's centre (sNew/2) to the origin, rotate, shift to the volume centre.
+    float back[12], rot[12], fwd[12], tmp[12];
+    set_identity(back); set_identity(rot); set_identity(fwd);
+    const float c = std::cos(theta), s = std::sin(theta);
+    long long s_new = 0;
+    if (rot_axis == 1) {
+        back[7] = (float)(sy / 2); back[11] = (float)(sz / 2);
+        rot[5] = c; rot[6] = s; rot[9] = -s; rot[10] = c;
+        s_new = (long long)std::round(std::sqrt((double)(sy * sy + sz * sz)));
+        fwd[7] = (float)(-s_new / 2); fwd[11] = (float)(-s_new / 2);
+    } else if (rot_axis == 2) {
+        back[3] = (float)(sx / 2); back[11] = (float)(sz / 2);
+        rot[0] = c; rot[2] = -s; rot[8] = s; rot[10] = c;
+        s_new = (long long)std::round(std::sqrt((double)(sx * sx + sz * sz)));
+        fwd[3] = (float)(-s_new / 2); fwd[11] = (float)(-s_new / 2);
+    } else if (rot_axis == 3) {
+        back[3] = (float)(sx / 2); back[7] = (float)(sy / 2);
+        rot[0] = c; rot[1] = s; rot[4] = -s; rot[5] = c;
+        s_new = (long long)std::round(std::sqrt((double)(sx * sx + sy * sy)));
+        fwd[3] = (float)(-s_new / 2); fwd[7] = (float)(-s_new / 2);
+    }
+    matrixmultiply(tmp, back, rot);
+    matrixmultiply(m, tmp, fwd);
+}
+
+bool check_matrix(const float *m, long long sx, long long sy, long long sz) {
+    const float scale_low = 0.5f, scale_up = 1.4f, sum_low = 2.f, sum_up = 4.f, shift_ratio = 0.8f;
+    bool ok = true;
+    if (m[0] < scale_low || m[0] > scale_up || m[5] < scale_low || m[5] > scale_up || m[10] < scale_low ||
+        m[10] > scale_up)
+        ok = false;
+    const float ssum = m[0] + m[5] + m[10];
+    if (ssum < sum_low || ssum > sum_up) ok = false;
+    if (std::fabs(m[3]) > shift_ratio * (float)sx || std::fabs(m[7]) > shift_ratio * (float)sy ||
+        std::fabs(m[11]) > shift_ratio * (float)sz)
+        ok = false;
+    return ok;
+}
+
+// ---------------------------------------------------------------------------
+// driver
+// ---------------------------------------------------------------------------
+namespace {
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, Dims dims,
+                        int aff_method, bool flag_tmx, float ftol, int it_limit, bool verbose, float *records,
+                        hipStream_t stream, const RegOptions &opt) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const size_t n = (size_t)dims.count();
+    k::Affine12 aff;  // the reference's global affCoef: matrix of the most recent cost evaluation
+
+    if (aff_method == 0) {  // no registration: apply the input matrix or copy (reference :2767-2781)
+        if (flag_tmx) {
+            std::memcpy(aff.m, iTmx, sizeof aff.m);
+            k::affine_resample(d_reg, d_img2, dims, dims, aff, stream);
+        } else {
+            MIL_HIP(hipMemcpyAsync(d_reg, d_img2, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            set_identity(iTmx);
+        }
+        MIL_HIP(hipStreamSynchronize(stream));
+        records[7] = (float)seconds_since(t_start);
+        if (verbose) printf("\t... no registration performed!\n");
+        return 0;
+    }
+    if (aff_method < 0 || aff_method > 7) throw Error(1, "reg3d_affine: affMethod must be 0..7");
+
+    float aff_initial[12];
+    set_identity(aff_initial);
+    float p12[12], xi12[12 * 12], p9[9] = {0, 0, 0, 0, 0, 0, 1, 1, 1}, xi9[9 * 9];
+    for (int i = 0; i < 12; ++i)
+        for (int j = 0; j < 12; ++j) xi12[i * 12 + j] = (i == j) ? 1.f : 0.f;
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) xi9[i * 9 + j] = (i == j) ? 1.f : 0.f;  // NOT reset between cascade stages
+
+    DeviceBuffer<float> src_ms(n), tgt_ms(n);
+    k::ReduceWorkspace red;
+    k::CorrWorkspace corr;
+
+    // source: optional pre-transform by the input matrix, then mean subtraction (:2817-2845)
+    const float *src_for_stats = d_img2;
+    if (flag_tmx) {
+        if (aff_method == 5) {
+            std::memcpy(aff_initial, iTmx, sizeof aff_initial);
+        } else {
+            std::memcpy(aff.m, iTmx, sizeof aff.m);
+            k::affine_resample(d_reg, d_img2, dims, dims, aff, stream);
+            src_for_stats = d_reg;
+        }
+    }
+    const double sum2 = k::reduce_sync(k::kSum, src_for_stats, n, 0.f, red, stream);
+    k::add_value(src_ms.get(), src_for_stats, -(float)sum2 / (float)n, n, stream);
+    const double sqr2 = k::reduce_sync(k::kSumSqShifted, src_ms.get(), n, 0.f, red, stream);
+    if ((float)std::sqrt(sqr2) == 0.f)
+        throw Error(-3, "reg3d_affine: SD of image 2 is zero (empty image, or empty after the initial transform)");
+    // target (:2859-2868)
+    const double sum1 = k::reduce_sync(k::kSum, d_img1, n, 0.f, red, stream);
+    const float mean1_neg = -(float)sum1 / (float)n;
+    k::add_value(tgt_ms.get(), d_img1, mean1_neg, n, stream);
+    const double sqr1 = k::reduce_sync(k::kSumSqShifted, tgt_ms.get(), n, 0.f, red, stream);
+    const float sd_t = (float)std::sqrt(sqr1);
+    if (sd_t == 0.f) throw Error(-3, "reg3d_affine: SD of image 1 is zero (empty image)");
+
+    int evals = 0;
+    bool dof9 = false;
+    int dof_num = 12;
+    CostFn cost = [&](const float *x) -> float {  // costfunc :2377-2388 + corrfunc :954-988
+        if (dof9) dof9tomatrix(aff.m, x, dof_num);
+        else p2matrix(aff.m, x);
+        double ss = 0, st = 0;
+        k::corr_sums_sync(tgt_ms.get(), src_ms.get(), dims, dims, aff, corr, stream, &ss, &st);
+        ++evals;
+        const double root = std::sqrt(ss);
+        const float zncc = (root == 0) ? -2.0f : (float)(st / root) / sd_t;
+        return -zncc;
+    };
+
+    matrix2p(p12, aff_initial);
+    const auto t_opt = std::chrono::steady_clock::now();
+    records[1] = -cost(p12);  // initial ZNCC (:2881)
+    records[4] = 0.f;
+    if (verbose) printf("\t... initial cross correlation value: %f;\n", records[1]);
+    evals = 0;
+
+    PowellResult r;
+    auto stage9 = [&](int n_dof, float tol) {
+        dof9 = true;
+        dof_num = n_dof;
+        r = powell_minimize(p9, xi9, 9, n_dof, tol, cost, &evals, it_limit);
+        if (opt.matrix_from_optimum) dof9tomatrix(aff.m, p9, n_dof);
+    };
+    auto stage12 = [&](float tol) {
+        dof9 = false;
+        dof_num = 12;
+        r = powell_minimize(p12, xi12, 12, 12, tol, cost, &evals, it_limit);
+        if (opt.matrix_from_optimum) p2matrix(aff.m, p12);
+    };
+    switch (aff_method) {
+    case 1: stage9(3, ftol); break;
+    case 2: stage9(6, ftol); break;
+    case 3: stage9(7, ftol); break;
+    case 4: stage9(9, ftol); break;
+    case 5: stage12(ftol); break;
+    case 6:  // rigid body first, then 12 DOF (:2915-2929)
+        stage9(6, (float)0.01);
+        records[2] = -r.fret;
+        if (verbose) printf("\t... cross correlation value after 6 DOF: %f;\n", -r.fret);
+        matrix2p(p12, aff.m);
+        stage12(ftol);
+        break;
+    case 7:  // 3 -> 6 -> 9 -> 12 DOF (:2930-2954)
+        stage9(3, (float)0.01);
+        if (verbose) printf("\t... cross correlation value after 3 DOF: %f;\n", -r.fret);
+        stage9(6, (float)0.01);
+        if (verbose) printf("\t... cross correlation value after 6 DOF: %f;\n", -r.fret);
+        stage9(9, (float)0.005);
+        records[2] = -r.fret;
+        if (verbose) printf("\t... cross correlation value after 9 DOF: %f;\n", -r.fret);
+        matrix2p(p12, aff.m);
+        stage12(ftol);
+        break;
+    }
+    if (flag_tmx && aff_method != 5) {  // compose with the input matrix (:2958-2961)
+        float composed[12];
+        matrixmultiply(composed, iTmx, aff.m);
+        std::memcpy(aff.m, composed, sizeof composed);
+    }
+    std::memcpy(iTmx, aff.m, sizeof aff.m);
+    records[3] = -r.fret;
+    records[5] = (float)evals;
+    records[6] = (float)seconds_since(t_opt);
+    if (verbose) {
+        printf("\t... optimized cross correlation value: %f;\n", records[3]);
+        printf("\t... total sub iteration number: %d;\n", evals);
+        printf("\t... time cost for all iterations: %f s;\n", records[6]);
+    }
+    // final resample of the RAW source (:2974-2977)
+    k::affine_resample(d_reg, d_img2, dims, dims, aff, stream);
+    MIL_HIP(hipStreamSynchronize(stream));
+    records[7] = (float)seconds_since(t_start);
+    if (verbose) printf("\t... time cost for registration: %f s;\n", records[7]);
+    return 0;
+}
+
+}  // namespace mil

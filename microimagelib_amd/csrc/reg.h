@@ -1,0 +1,31 @@
+// 3-D affine registration on device-resident volumes: parameterisations, the
+// correlation cost driven by Powell, and the final resample.
+#pragma once
+
+#include "kernels.h"
+
+namespace mil {
+
+// 3x4 row-major affine helpers (0-based parameter vectors).
+void p2matrix(float *m, const float *p12);                         // reference src/api_subfunc.cu:557
+void matrix2p(float *p12, const float *m);                         // :569
+void matrixmultiply(float *m, const float *m1, const float *m2);   // :584
+void dof9tomatrix(float *m, const float *p9, int dof_num);         // :715
+void rot2matrix(float *m, float theta, long long sx, long long sy, long long sz, int rot_axis);  // :626
+bool check_matrix(const float *m, long long sx, long long sy, long long sz);                     // api_reg.cpp:247
+
+struct RegOptions {
+    // false (default): hand back / resample with the matrix of the LAST cost evaluation, as the
+    // reference does through its global affCoef.  true: recompute from the
+    // optimiser's final parameter vector.
+    bool matrix_from_optimum = false;
+};
+
+// reg3d_affine1, reference src/api_subfunc.cu:2733-2994.  d_img1 = target, d_img2 = source,
+// both `dims`; d_reg receives the resampled source.  records: >= 8 floats ([1..7] written).
+// Throws Error; returns 0.
+int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, Dims dims,
+                        int aff_method, bool flag_tmx, float ftol, int it_limit, bool verbose, float *records,
+                        hipStream_t stream, const RegOptions &opt = RegOptions());
+
+}  // namespace mil

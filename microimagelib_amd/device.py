@@ -1,0 +1,209 @@
+"""Device-resident front end over ``include/mil_device.h`` for hosts that keep volumes
+in HBM (the batch driver, bench.py, the parity tests).  PyTorch is used only as the
+owner of device memory / streams; all compute is in ``libapi.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t: torch.Tensor) -> int:
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("expected a contiguous device tensor")
+    return t.data_ptr()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with status {rc}")
+
+
+def _stream_ptr(stream) -> int:
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return int(stream.cuda_stream)
+
+
+# ---- raw kernels -----------------------------------------------------------------
+def rl_ratio_(T: torch.Tensor, A: torch.Tensor, stream=None):
+    _check(_lib.load().mil_rl_ratio(_ptr(T), _ptr(A), T.numel(), _stream_ptr(stream)), "mil_rl_ratio")
+    return T
+
+
+def rl_update_(E: torch.Tensor, T: torch.Tensor, eps: float = 0.01, stream=None):
+    _check(_lib.load().mil_rl_update(_ptr(E), _ptr(T), E.numel(), float(eps), _stream_ptr(stream)), "mil_rl_update")
+    return E
+
+
+def cmul_(S: torch.Tensor, otf: torch.Tensor, stream=None):
+    assert S.dtype == torch.complex64 and otf.dtype == torch.complex64
+    _check(_lib.load().mil_cmul(_ptr(S), _ptr(otf), S.numel(), _stream_ptr(stream)), "mil_cmul")
+    return S
+
+
+def sum_f64(a: torch.Tensor, stream=None) -> float:
+    out = C.c_double(0)
+    _check(_lib.load().mil_sum_f64(_ptr(a), a.numel(), C.byref(out), _stream_ptr(stream)), "mil_sum_f64")
+    return out.value
+
+
+def _dims(t):  # tensor [z][y][x] -> (nx, ny, nz)
+    return int(t.shape[2]), int(t.shape[1]), int(t.shape[0])
+
+
+def pad_psf(psf: torch.Tensor, box_shape, scale=1.0, flip=False, stream=None):
+    out = torch.empty(tuple(box_shape), dtype=torch.float32, device=psf.device)
+    _check(_lib.load().mil_pad_psf(_ptr(out), _ptr(psf), *_dims(out), *_dims(psf), float(scale), int(flip),
+                                   _stream_ptr(stream)), "mil_pad_psf")
+    return out
+
+
+def pad_stack(a: torch.Tensor, box_shape, stream=None):
+    out = torch.empty(tuple(box_shape), dtype=torch.float32, device=a.device)
+    _check(_lib.load().mil_pad_stack(_ptr(out), _ptr(a), *_dims(out), *_dims(a), _stream_ptr(stream)), "mil_pad_stack")
+    return out
+
+
+def crop_stack(a: torch.Tensor, shape, stream=None):
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=a.device)
+    _check(_lib.load().mil_crop_stack(_ptr(out), _ptr(a), *_dims(out), *_dims(a), _stream_ptr(stream)),
+           "mil_crop_stack")
+    return out
+
+
+def align_size(a: torch.Tensor, shape, stream=None):
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=a.device)
+    _check(_lib.load().mil_align_size(_ptr(out), _ptr(a), *_dims(out), *_dims(a), _stream_ptr(stream)),
+           "mil_align_size")
+    return out
+
+
+def flip3(a: torch.Tensor, stream=None):
+    out = torch.empty_like(a)
+    _check(_lib.load().mil_flip3(_ptr(out), _ptr(a), *_dims(a), _stream_ptr(stream)), "mil_flip3")
+    return out
+
+
+def rot_y90(a: torch.Tensor, direction: int, stream=None):
+    out = torch.empty((a.shape[2], a.shape[1], a.shape[0]), dtype=torch.float32, device=a.device)
+    _check(_lib.load().mil_rot_y90(_ptr(out), _ptr(a), *_dims(a), int(direction), _stream_ptr(stream)), "mil_rot_y90")
+    return out
+
+
+def max_projection(a: torch.Tensor, direction: int, stream=None):
+    sz, sy, sx = a.shape
+    shape = {1: (sy, sx), 2: (sx, sz), 3: (sz, sy)}[direction]
+    out = torch.empty(shape, dtype=torch.float32, device=a.device)
+    _check(_lib.load().mil_max_projection(_ptr(out), _ptr(a), *_dims(a), int(direction), _stream_ptr(stream)),
+           "mil_max_projection")
+    return out
+
+
+def affine_resample(src: torch.Tensor, m12, out_shape, stream=None):
+    out = torch.empty(tuple(out_shape), dtype=torch.float32, device=src.device)
+    m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)
+    _check(_lib.load().mil_affine_resample(_ptr(out), _ptr(src), *_dims(out), *_dims(src),
+                                           m.ctypes.data_as(_lib.c_float_p), _stream_ptr(stream)),
+           "mil_affine_resample")
+    return out
+
+
+def corr_sums(target: torch.Tensor, src: torch.Tensor, m12, stream=None):
+    m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)
+    out = (C.c_double * 2)()
+    _check(_lib.load().mil_corr_sums(_ptr(target), _ptr(src), *_dims(target), *_dims(src),
+                                     m.ctypes.data_as(_lib.c_float_p), out, _stream_ptr(stream)), "mil_corr_sums")
+    return out[0], out[1]
+
+
+def reg3d_affine(target: torch.Tensor, source: torch.Tensor, aff_method=6, i_tmx=None, flag_tmx=False, ftol=1e-4,
+                 it_limit=3000, verbose=False, stream=None):
+    """reg3d_affine1 on device-resident volumes.  Returns (registered, tmx[12], records[11])."""
+    reg = torch.empty_like(target)
+    tmx = np.zeros(12, dtype=np.float32)
+    if i_tmx is not None:
+        tmx[:] = np.asarray(i_tmx, dtype=np.float32).reshape(12)
+    rec = np.zeros(11, dtype=np.float32)
+    _check(_lib.load().mil_reg3d_affine(_ptr(reg), tmx.ctypes.data_as(_lib.c_float_p), _ptr(target), _ptr(source),
+                                        *_dims(target), int(aff_method), int(flag_tmx), float(ftol), int(it_limit),
+                                        int(verbose), rec.ctypes.data_as(_lib.c_float_p), _stream_ptr(stream)),
+           "mil_reg3d_affine")
+    return reg, tmx, rec
+
+
+# ---- deconvolution engine ----------------------------------------------------------
+class DeconEngine:
+    """RL engine for one FFT box (shape ``(nz, ny, nx)``) on the current device."""
+
+    TIMER_UPDATE, TIMER_RATIO, TIMER_CMUL, TIMER_FFT = 0, 1, 2, 3
+
+    def __init__(self, box_shape, stream=None):
+        self._lib = _lib.load()
+        self.box_shape = tuple(int(s) for s in box_shape)
+        nz, ny, nx = self.box_shape
+        h = C.c_void_p()
+        # The engine runs on its own (non-default) HIP stream; `_enter` orders it after whatever
+        # the caller enqueued on torch's current stream, `sync` makes results visible to the host.
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        _check(self._lib.mil_decon_create(C.byref(h), nx, ny, nz, int(self.stream.cuda_stream)), "mil_decon_create")
+        self._h = h
+        self.spectrum_shape = (nz, ny, nx // 2 + 1)
+
+    def _enter(self):
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mil_decon_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def gen_otf(self, psf: torch.Tensor, flip=False) -> torch.Tensor:
+        otf = torch.empty(self.spectrum_shape, dtype=torch.complex64, device=psf.device)
+        px, py, pz = _dims(psf)
+        self._enter()
+        _check(self._lib.mil_decon_gen_otf(self._h, _ptr(otf), _ptr(psf), px, py, pz, int(flip)), "mil_decon_gen_otf")
+        return otf
+
+    def init_single(self, A, E, const_init=False):
+        self._enter()
+        _check(self._lib.mil_decon_init_single(self._h, _ptr(A), _ptr(E), int(const_init)), "mil_decon_init_single")
+
+    def init_dual(self, A, B, E, const_init=False):
+        self._enter()
+        _check(self._lib.mil_decon_init_dual(self._h, _ptr(A), _ptr(B), _ptr(E), int(const_init)),
+               "mil_decon_init_dual")
+
+    def run_single(self, E, A, otf, otf_bp, iters):
+        self._enter()
+        _check(self._lib.mil_decon_run_single(self._h, _ptr(E), _ptr(A), _ptr(otf), _ptr(otf_bp), int(iters)),
+               "mil_decon_run_single")
+
+    def run_dual(self, E, A, B, otf1, otf2, otf_bp1, otf_bp2, iters):
+        self._enter()
+        _check(self._lib.mil_decon_run_dual(self._h, _ptr(E), _ptr(A), _ptr(B), _ptr(otf1), _ptr(otf2),
+                                            _ptr(otf_bp1), _ptr(otf_bp2), int(iters)), "mil_decon_run_dual")
+
+    def sync(self):
+        _check(self._lib.mil_decon_sync(self._h), "mil_decon_sync")
+
+    def timer_enable(self, which, enable=True):
+        _check(self._lib.mil_decon_timer_enable(self._h, int(which), int(enable)), "mil_decon_timer_enable")
+
+    def timer_read(self, which):
+        ms = C.c_double(0)
+        n = C.c_size_t(0)
+        _check(self._lib.mil_decon_timer_read(self._h, int(which), C.byref(ms), C.byref(n)), "mil_decon_timer_read")
+        return ms.value, n.value
