@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Richardson-Lucy iterations/s on a 512x512x256 float32 volume.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one single-view RL iteration (forward projection, ratio, back projection,
+estimate update: reference src/api_subfunc.cu:3404-3416) on one 512x512x256 volume per
+GPU, inputs resident in HBM (BASELINE.json configs[1]).  N > 1: one process per GPU
+(torch.distributed, RCCL), every rank deconvolves its own time point -- weak scaling, no
+collective on the data path; the only exchange is the gather of the XY maximum-intensity
+projections to rank 0 after the timed region.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      HBM roofline of the fused estimate-update kernel, timed with HIP events on
+                the engine's stream inside the timed region;
+  cpu_baseline  the oracle's NumPy restatement of the same RL iteration timed on this box's
+                host cores (N = 1 only), a bounded sample;
+  extra         dual-view it/s, reg3D voxels/s and the per-kernel-family time split.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SHAPE = (256, 512, 512)  # (nz, ny, nx): imSize = {512, 512, 256}
+PSF_SHAPE = (64, 64, 64)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_volume(torch, shape, psf, seed):
+    """Blob phantom blurred by the PSF + Poisson noise, generated on the device (data
+    synthesis only; torch.fft is not part of the measured path)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    pts = torch.zeros(shape, device="cuda")
+    n_blobs = 200
+    idx = [torch.randint(0, s, (n_blobs,), device="cuda", generator=g) for s in shape]
+    amp = torch.rand(n_blobs, device="cuda", generator=g) * 1800 + 200
+    pts[idx[0], idx[1], idx[2]] = amp * 60
+    # blob shape: isotropic Gaussian sigma 3; then the view PSF
+    def gauss_kernel(sig):
+        ax = [torch.arange(s, device="cuda", dtype=torch.float32) for s in shape]
+        ax = [torch.minimum(a, s - a) for a, s in zip(ax, shape)]
+        k = (torch.exp(-0.5 * (ax[0] / sig[0]) ** 2)[:, None, None] * torch.exp(-0.5 * (ax[1] / sig[1]) ** 2)[None, :, None]
+             * torch.exp(-0.5 * (ax[2] / sig[2]) ** 2)[None, None, :])
+        return k / k.sum()
+    spec = torch.fft.rfftn(pts) * torch.fft.rfftn(gauss_kernel((3.0, 3.0, 3.0))) * torch.fft.rfftn(gauss_kernel(psf))
+    vol = torch.fft.irfftn(spec, s=shape).clamp_(min=0) + 100.0
+    del spec, pts
+    noisy = torch.poisson(vol, generator=g)
+    return noisy.float().contiguous()
+
+
+def cpu_baseline(img_host, psf_host, iters):
+    """Oracle (NumPy restatement of decon_singleview_OTF1) on the host: `iters` RL iterations."""
+    from oracle import decon_oracle as do
+    F = img_host.shape
+    otf = do.gen_otf(psf_host, F)
+    otf_bp = do.gen_otf(do.flip3(psf_host), F)
+    A = do.clamp_small(img_host)
+    E = A.copy()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        E = do.rl_view_update(E, A, otf, otf_bp, F)
+    dt = time.perf_counter() - t0
+    return iters / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (got WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from microimagelib_amd import _lib, device as mdev
+    lib = _lib.load()
+    assert lib.mil_set_device(local_rank) == 0
+
+    from oracle.decon_oracle import gaussian_psf  # PSF definition shared with the tests (tiny, host side)
+    psf_a_host = gaussian_psf(PSF_SHAPE, (6.0, 2.5, 2.5))  # sigma (z, y, x)
+    psf_b_host = gaussian_psf(PSF_SHAPE, (2.5, 2.5, 6.0))
+    psf_a = torch.from_numpy(psf_a_host).cuda()
+    psf_b = torch.from_numpy(psf_b_host).cuda()
+
+    # each rank = one time point of the batch (seeded per rank)
+    img_a = synth_volume(torch, SHAPE, (6.0, 2.5, 2.5), seed=100 + rank)
+    n_real = img_a.numel()
+    R = 4 * n_real
+    C = 8 * SHAPE[0] * SHAPE[1] * (SHAPE[2] // 2 + 1)
+
+    eng = mdev.DeconEngine(SHAPE)
+    otf_a = eng.gen_otf(psf_a)
+    bp_a = eng.gen_otf(psf_a, flip=True)
+    A = img_a.clone()
+    E = torch.empty_like(A)
+    eng.init_single(A, E)
+    eng.run_single(E, A, otf_a, bp_a, args.warmup)
+    eng.sync()
+
+    for w in (mdev.DeconEngine.TIMER_UPDATE, mdev.DeconEngine.TIMER_RATIO, mdev.DeconEngine.TIMER_CMUL,
+              mdev.DeconEngine.TIMER_FFT):
+        eng.timer_enable(w, True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    eng.run_single(E, A, otf_a, bp_a, args.steps)  # EXACTLY K steps
+    eng.sync()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    upd_ms, upd_n = eng.timer_read(mdev.DeconEngine.TIMER_UPDATE)
+    rat_ms, rat_n = eng.timer_read(mdev.DeconEngine.TIMER_RATIO)
+    cm_ms, cm_n = eng.timer_read(mdev.DeconEngine.TIMER_CMUL)
+    fft_ms, fft_n = eng.timer_read(mdev.DeconEngine.TIMER_FFT)
+    for w in range(4):
+        eng.timer_enable(w, False)
+
+    # ---- gather of the MIP stack (the only inter-GPU exchange of the batch) ------------
+    mip = mdev.max_projection(E, 1)  # XY MIP, 512x512 float32
+    mip_checksum = float(mip.double().sum().item())
+    if distributed:
+        stack = [torch.empty_like(mip) for _ in range(world)] if rank == 0 else None
+        dist.gather(mip, gather_list=stack, dst=0)
+        if rank == 0:
+            mip_checksum = float(sum(float(m.double().sum().item()) for m in stack))
+
+    result = None
+    if rank == 0:
+        value = world * args.steps / elapsed
+        upd_avg_ms = upd_ms / max(upd_n, 1)
+        achieved = 3 * R / (upd_avg_ms * 1e-3) / 1e9 if upd_n else None
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("rl_update_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "RL iterations/s, 512x512x256 float32, single view",
+            "value": round(value, 3),
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "deconSingleView 512x512x256 float32, RL iterations, 1 MI355X (BASELINE.json configs[1])",
+                "psf": "64x64x64 anisotropic Gaussian, matched back projector",
+                "volumes_per_gpu": 1,
+                "sharding": "one time-point volume per GPU, no data-path collective; XY-MIP gather over RCCL after the timed region",
+            },
+            "roofline": {
+                "kernel": "rl_update (E = max(E*T, 0.01), fused multiply+clamp)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1) if achieved else None,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": 3 * R,
+                "avg_launch_ms": round(upd_avg_ms, 5),
+                "launches": int(upd_n),
+            },
+            "extra": {
+                "kernel_ms_per_launch": {
+                    "rl_update": round(upd_ms / max(upd_n, 1), 5),
+                    "rl_ratio": round(rat_ms / max(rat_n, 1), 5),
+                    "cmul_otf": round(cm_ms / max(cm_n, 1), 5),
+                    "rocfft_execute": round(fft_ms / max(fft_n, 1), 5),
+                },
+                "hbm_gbs": {
+                    "rl_ratio": round(3 * R / (rat_ms / max(rat_n, 1) * 1e-3) / 1e9, 1) if rat_n else None,
+                    "cmul_otf": round(3 * C / (cm_ms / max(cm_n, 1) * 1e-3) / 1e9, 1) if cm_n else None,
+                },
+                "iteration_algorithmic_bytes": 4 * (R + C) + 2 * 3 * C + 3 * R + 3 * R,
+                "iteration_hbm_roofline_frac": round((4 * (R + C) + 6 * C + 6 * R) / (elapsed / args.steps) / 1e9
+                                                     / HBM_PEAK_GBS, 4),
+                "mip_checksum": mip_checksum,
+            },
+        }
+
+    # ---- supplementary: dual view + registration (N = 1 only) ---------------------------
+    if world == 1 and not args.no_extra:
+        img_b = synth_volume(torch, SHAPE, (2.5, 2.5, 6.0), seed=200)
+        otf_b = eng.gen_otf(psf_b)
+        bp_b = eng.gen_otf(psf_b, flip=True)
+        B = img_b.clone()
+        eng.init_dual(A, B, E)
+        eng.run_dual(E, A, B, otf_a, otf_b, bp_a, bp_b, 2)
+        eng.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run_dual(E, A, B, otf_a, otf_b, bp_a, bp_b, args.steps)
+        eng.sync()
+        dual_s = time.perf_counter() - t0
+        result["extra"]["dualview_iterations_per_s"] = round(args.steps / dual_s, 3)
+        del B, img_b, otf_b, bp_b
+
+        # registration: source = target warped by a known matrix (rotation 3 deg about y, scale 1.02, shift)
+        c, s = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+        lin = 1.02 * np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+        centre = np.array([SHAPE[2] / 2, SHAPE[1] / 2, SHAPE[0] / 2])  # (x, y, z)
+        shift = centre - lin @ centre + np.array([5.0, -3.0, 2.0])      # rotate / scale about the volume centre
+        known = np.concatenate([lin, shift[:, None]], axis=1).astype(np.float32).reshape(12)
+        target = img_a
+        source = mdev.affine_resample(target, known, SHAPE)
+        torch.cuda.synchronize()
+        reg, tmx, rec = mdev.reg3d_affine(target, source, aff_method=7, ftol=1e-4, it_limit=3000)
+        evals, opt_s = float(rec[5]), float(rec[6])
+        result["extra"]["reg3d"] = {
+            "workload": "reg3D 12-DOF cascade (affMethod 7), Powell + correlation cost, 512x512x256",
+            "voxels_per_s": round(n_real * evals / opt_s, 1) if opt_s > 0 else None,
+            "cost_evaluations": int(evals),
+            "evaluations_per_s": round(evals / opt_s, 2) if opt_s > 0 else None,
+            "optimisation_s": round(opt_s, 3),
+            "zncc_initial": round(float(rec[1]), 5),
+            "zncc_final": round(float(rec[3]), 5),
+            "hbm_roofline_frac_per_eval": round(2 * R * evals / opt_s / 1e9 / HBM_PEAK_GBS, 4) if opt_s > 0 else None,
+        }
+        del reg, source
+
+    if world == 1 and not args.no_cpu_baseline and rank == 0:
+        img_host = img_a.cpu().numpy()
+        del E, A
+        torch.cuda.empty_cache()
+        its, secs = cpu_baseline(img_host, psf_a_host, args.cpu_iters)
+        result["cpu_baseline"] = {
+            "value": round(its, 4),
+            "unit": "iterations/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{args.cpu_iters} RL iterations of the same 512x512x256 volume and PSF "
+                      f"(oracle/decon_oracle.py: NumPy pocketfft float32 + single-threaded element-wise), {secs:.1f} s",
+            "host_cores_available": os.cpu_count(),
+        }
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    eng.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

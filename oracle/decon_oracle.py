@@ -107,6 +107,12 @@ def crop_stack(a: np.ndarray, shape) -> np.ndarray:
     return np.ascontiguousarray(a[tuple(sl)])
 
 
+def clamp_small(a: np.ndarray) -> np.ndarray:
+    """maxvalue3Dgpukernel, include/cukernel.cuh:383-392: ``(v > eps) ? v : eps`` -- a NaN
+    collapses to eps (np.maximum would propagate it)."""
+    return np.where(a > SMALLVALUE, a, SMALLVALUE).astype(np.float32)
+
+
 def sum_f64(a: np.ndarray) -> float:
     """sum3Dgpu, src/api_subfunc.cu:386-402: float64 accumulation of a float32 volume."""
     return float(np.sum(a, dtype=np.float64))
@@ -121,7 +127,7 @@ def r2c(a: np.ndarray) -> np.ndarray:
 
 
 def c2r(s: np.ndarray, F) -> np.ndarray:
-    out = np.fft.irfftn(s, s=F, norm="forward")  # norm="forward": inverse is unscaled
+    out = np.fft.irfftn(s, s=F, axes=(0, 1, 2), norm="forward")  # norm="forward": inverse is unscaled
     return out.astype(np.float32, copy=False)
 
 
@@ -163,13 +169,13 @@ def rl_view_update(E, M, otf, otf_bp, F):
     T = M / T  # div3Dgpu, unguarded  :3409
     T = c2r(cmul(r2c(T), otf_bp), F)
     E = E * T  # multi3Dgpu  :3414
-    return np.maximum(E, SMALLVALUE)  # maxvalue3Dgpu  :3415
+    return clamp_small(E)  # maxvalue3Dgpu  :3415
 
 
 def decon_singleview_otf(A, otf, otf_bp, iters: int, const_init: bool):
     """decon_singleview_OTF1, src/api_subfunc.cu:3361-3430, on an FFT-sized volume."""
     F = A.shape
-    A = np.maximum(A.astype(np.float32), SMALLVALUE)  # :3380
+    A = clamp_small(A.astype(np.float32))  # :3380
     if const_init:
         mean_value = np.float32(sum_f64(A))  # (float)sum3Dgpu -- the SUM  :3382
         E = np.full(F, mean_value, dtype=np.float32)  # :3383-3384
@@ -183,8 +189,8 @@ def decon_singleview_otf(A, otf, otf_bp, iters: int, const_init: bool):
 def decon_dualview_otf(A, B, otf1, otf2, otf_bp1, otf_bp2, iters: int, const_init: bool):
     """decon_dualview_OTF1, src/api_subfunc.cu:3587-3674."""
     F = A.shape
-    A = np.maximum(A.astype(np.float32), SMALLVALUE)  # :3606
-    B = np.maximum(B.astype(np.float32), SMALLVALUE)  # :3607
+    A = clamp_small(A.astype(np.float32))  # :3606
+    B = clamp_small(B.astype(np.float32))  # :3607
     if const_init:
         m1 = np.float32(sum_f64(A))  # :3610
         m2 = np.float32(sum_f64(B))  # :3611
@@ -243,7 +249,7 @@ def rl_ratio(A, T):
 
 def rl_update(E, T):
     """multi3Dkernel + maxvalue3Dgpukernel, include/cukernel.cuh:115-126, 383-392."""
-    return np.maximum(E * T, SMALLVALUE).astype(np.float32)
+    return clamp_small((E * T).astype(np.float32))
 
 
 # --------------------------------------------------------------------------
@@ -284,7 +290,7 @@ def blur(vol: np.ndarray, psf: np.ndarray) -> np.ndarray:
     p /= p.sum()
     padded = pad_psf(align_size(p, vol.shape) if any(a < b for a, b in zip(vol.shape, p.shape)) else p,
                      vol.shape)
-    out = np.fft.irfftn(np.fft.rfftn(vol.astype(np.float64)) * np.fft.rfftn(padded), s=vol.shape)
+    out = np.fft.irfftn(np.fft.rfftn(vol.astype(np.float64)) * np.fft.rfftn(padded), s=vol.shape, axes=(0, 1, 2))
     return out.astype(np.float32)
 
 

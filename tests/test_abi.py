@@ -1,0 +1,78 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol that
+include/libapi.h and include/mil_device.h declare (no compute is attempted here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    text = text.replace('extern "C" {', " ")
+    names = []
+    for stmt in text.split(";"):
+        stmt = " ".join(stmt.split())
+        if stmt.startswith("typedef") or "(" not in stmt:
+            continue
+        m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*\(", stmt)
+        if m:
+            names.append(m.group(1))
+    return names
+
+
+@pytest.mark.parametrize("header", ["libapi.h", "mil_device.h"])
+def test_every_declared_symbol_is_exported(lib, header):
+    names = declared_functions(header)
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"{header}: not exported: {missing}"
+
+
+def test_python_signature_table_covers_headers():
+    from microimagelib_amd import _lib
+    declared = set(declared_functions("libapi.h")) | set(declared_functions("mil_device.h"))
+    assert declared <= set(_lib.SIGNATURES), sorted(declared - set(_lib.SIGNATURES))
+
+
+def test_reference_cli_symbols_present(lib):
+    """Symbols the reference CLIs reference."""
+    for name in ("gettifinfo", "readtifstack", "writetifstack", "fexists", "concat", "decon_singleview",
+                 "decon_dualview", "reg3d", "imresize3d", "imoperation3D", "queryDevice", "checkmatrix", "mp2dgpu",
+                 "mip3dgpu"):
+        assert hasattr(lib, name)
+
+
+def test_library_reports_no_fallback_when_missing(tmp_path, monkeypatch):
+    from microimagelib_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libapi.so"))
+    with pytest.raises(ImportError):
+        _lib.load()
+
+
+def test_snap_transform_size_table(lib):
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tables.npz"))
+    for n, want in zip(g["snap_in"], g["snap_out"]):
+        assert lib.mil_snap_transform_size(int(n)) == int(want)
+    # SURVEY.md section 4.3
+    for n, want in ((20, 32), (36, 64), (50, 64), (100, 128), (128, 128), (130, 192), (256, 256), (300, 320),
+                    (500, 512), (512, 512)):
+        assert lib.mil_snap_transform_size(n) == want
+
+
+def test_concat_and_fexists(lib, tmp_path):
+    lib.concat.restype = ctypes.c_void_p
+    p = lib.concat(3, ctypes.c_char_p(b"ab"), ctypes.c_char_p(b""), ctypes.c_char_p(b"cde"))
+    assert ctypes.string_at(p) == b"abcde"
+    ctypes.CDLL(None).free(ctypes.c_void_p(p))
+    f = tmp_path / "x.txt"
+    assert not lib.fexists(str(f).encode())
+    f.write_text("1")
+    assert lib.fexists(str(f).encode())

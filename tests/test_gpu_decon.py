@@ -1,0 +1,218 @@
+"""GPU parity of the Richardson-Lucy path: libapi.h entry points (host pointers) and
+the device-resident engine, against the oracle, the committed golden vectors and
+size-independent properties at the benchmark size.
+
+Tolerance (BASELINE.json north_star): 1e-5 relative, float32.  The RL estimate is
+clamped at 0.01 and spans 0.01 .. ~3000, and FFT rounding is proportional to the
+volume's scale, so the metric is  max|a-b| / max(|b|, floor)  with floor = the volume's
+mean magnitude ("relative metric that has an absolute floor")."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import decon_oracle as do
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+f32 = np.float32
+RTOL = 1e-5
+
+
+def rel_err(got, want):
+    want = want.astype(np.float64)
+    floor = float(np.mean(np.abs(want)))
+    return float(np.max(np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), floor)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from microimagelib_amd import api
+    return api
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from microimagelib_amd import device
+    return device
+
+
+def T(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------- golden vectors, host API
+def test_golden_singleview_small(api):
+    g = np.load(os.path.join(GOLD, "decon_sv_small.npz"))
+    out, rec = api.decon_singleview(g["img"], g["psf"], int(g["iters"]))
+    assert rel_err(out, g["expected"]) < RTOL
+    assert rec[0] == 1
+    out, _ = api.decon_singleview(g["img"], g["psf"], int(g["iters"]), const_init=True)
+    assert rel_err(out, g["expected_const"]) < RTOL
+
+
+def test_golden_dualview_small(api):
+    g = np.load(os.path.join(GOLD, "decon_dv_small.npz"))
+    out, _ = api.decon_dualview(g["img1"], g["img2"], g["psf1"], g["psf2"], int(g["iters"]))
+    assert rel_err(out, g["expected"]) < RTOL
+    out, _ = api.decon_dualview(g["img1"], g["img2"], g["psf1"], g["psf2"], int(g["iters"]), const_init=True)
+    assert rel_err(out, g["expected_const"]) < RTOL
+
+
+def test_golden_psf_equals_fft_box(api):
+    g = np.load(os.path.join(GOLD, "decon_sv_psf_eq_fft.npz"))
+    out, _ = api.decon_singleview(g["img"], g["psf"], int(g["iters"]))
+    assert rel_err(out, g["expected"]) < RTOL
+
+
+def test_golden_unmatched_back_projector(api):
+    g = np.load(os.path.join(GOLD, "decon_sv_unmatched.npz"))
+    out, _ = api.decon_singleview(g["img"], g["psf"], int(g["iters"]), unmatch=True, psf_bp=g["psf_bp"])
+    assert rel_err(out, g["expected"]) < RTOL
+
+
+def test_golden_psf_larger_than_box(api):
+    g = np.load(os.path.join(GOLD, "decon_sv_bigpsf.npz"))
+    out, _ = api.decon_singleview(g["img"], g["psf"], int(g["iters"]))
+    assert rel_err(out, g["expected"]) < RTOL
+
+
+@pytest.mark.parametrize("tag", ["odd", "even"])
+def test_golden_otf(dev, tag):
+    g = np.load(os.path.join(GOLD, f"otf_{tag}.npz"))
+    eng = dev.DeconEngine(tuple(int(v) for v in g["box"]))
+    psf = T(g["psf"])
+    for flip, key in ((False, "otf"), (True, "otf_flipped")):
+        got = eng.gen_otf(psf, flip=flip)
+        eng.sync()
+        got = got.cpu().numpy()
+        scale = float(np.max(np.abs(g[key])))
+        assert float(np.max(np.abs(got - g[key]))) / scale < 2e-6
+    eng.close()
+
+
+# ---------------------------------------------------------------- error behaviour of the C API
+def test_cpu_mode_is_refused(api):
+    img = np.ones((16, 16, 16), dtype=f32)
+    psf = np.ones((3, 3, 3), dtype=f32)
+    with pytest.raises(api.LibApiError) as e:
+        api.decon_singleview(img, psf, 1, gpu_mem_mode=0)
+    assert e.value.code == 1
+    with pytest.raises(api.LibApiError) as e:
+        api.decon_dualview(img, img, psf, psf, 1, gpu_mem_mode=0)
+    assert e.value.code == -1
+    with pytest.raises(api.LibApiError) as e:
+        api.decon_singleview(img, psf, 1, gpu_mem_mode=7)  # reference src/api_decon.cpp:316-318
+    assert e.value.code == 1
+    with pytest.raises(api.LibApiError) as e:
+        api.decon_dualview(img, img, psf, psf, 1, gpu_mem_mode=7)  # :685-687
+    assert e.value.code == -1
+
+
+def test_memory_mode_2_runs_as_mode_1(api):
+    g = np.load(os.path.join(GOLD, "decon_sv_psf_eq_fft.npz"))
+    out, rec = api.decon_singleview(g["img"], g["psf"], 2, gpu_mem_mode=2)
+    assert rec[0] == 1
+    assert rel_err(out, do.decon_singleview(g["img"], g["psf"], 2)) < RTOL
+
+
+def test_zero_iterations_returns_clamped_input(api):
+    rng = np.random.default_rng(0)
+    img = rng.uniform(-1, 5, (16, 32, 32)).astype(f32)
+    psf = do.gaussian_psf((5, 5, 5), (1, 1, 1))
+    out, _ = api.decon_singleview(img, psf, 0)
+    assert np.array_equal(out, do.clamp_small(img))
+
+
+# ---------------------------------------------------------------- known answers from the algorithm
+def test_delta_psf_is_identity(api):
+    """RL with a delta PSF leaves E = max(A, 0.01)."""
+    img = do.synthetic_view((32, 64, 64), do.gaussian_psf((9, 9, 9), (2, 1.5, 1.5)), n_blobs=10)
+    psf = np.zeros((7, 7, 7), dtype=f32)
+    psf[3, 3, 3] = 5.0
+    out, _ = api.decon_singleview(img, psf, 6)
+    assert rel_err(out, do.clamp_small(img)) < 5e-6
+
+
+def test_constant_init_scale_cancels(api):
+    """The 'mean' init is really the SUM; after one RL step any constant scale cancels
+    analytically, so const-init equals an init with constant 1 up to rounding."""
+    psf = do.gaussian_psf((9, 9, 9), (2, 1.5, 1.5))
+    img = do.synthetic_view((32, 64, 64), psf, n_blobs=10)
+    a, _ = api.decon_singleview(img, psf, 3, const_init=True)
+    F = img.shape
+    otf = do.gen_otf(psf, F)
+    otf_bp = do.gen_otf(do.flip3(psf), F)
+    A = do.clamp_small(img)
+    E = np.ones(F, dtype=f32)
+    for _ in range(3):
+        E = do.rl_view_update(E, A, otf, otf_bp, F)
+    assert rel_err(a, E) < 2e-5
+
+
+# ---------------------------------------------------------------- oracle, mid size, engine path
+@pytest.mark.parametrize("dual", [False, True])
+def test_engine_vs_oracle_128(dev, dual):
+    """Config 1 of BASELINE.json (128^3, 10 iterations) through the device-resident engine."""
+    import torch
+    shape = (128, 128, 128)
+    psf_a = do.gaussian_psf((32, 32, 32), (3.0, 1.5, 1.5))
+    psf_b = do.gaussian_psf((32, 32, 32), (1.5, 1.5, 3.0))
+    img_a = do.synthetic_view(shape, psf_a, seed=0, noise_seed=1)
+    img_b = do.synthetic_view(shape, psf_b, seed=0, noise_seed=2)
+    eng = dev.DeconEngine(shape)
+    A, B = T(img_a), T(img_b)
+    E = torch.empty_like(A)
+    otf_a, bp_a = eng.gen_otf(T(psf_a)), eng.gen_otf(T(psf_a), flip=True)
+    if dual:
+        otf_b, bp_b = eng.gen_otf(T(psf_b)), eng.gen_otf(T(psf_b), flip=True)
+        eng.init_dual(A, B, E)
+        eng.run_dual(E, A, B, otf_a, otf_b, bp_a, bp_b, 10)
+        want = do.decon_dualview(img_a, img_b, psf_a, psf_b, 10)
+    else:
+        eng.init_single(A, E)
+        eng.run_single(E, A, otf_a, bp_a, 10)
+        want = do.decon_singleview(img_a, psf_a, 10)
+    eng.sync()
+    got = E.cpu().numpy()
+    eng.close()
+    assert rel_err(got, want) < RTOL
+
+
+# ---------------------------------------------------------------- benchmark size, properties only
+def test_full_size_properties(dev):
+    """512x512x256 (BASELINE.json config 2): the oracle is too slow here, so check
+    size-independent properties: delta-PSF identity, flux behaviour and determinism."""
+    import torch
+    shape = (256, 512, 512)
+    eng = dev.DeconEngine(shape)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.rand(shape, device="cuda", generator=g) * 1000 + 1
+    A0 = A.clone()
+    E = torch.empty_like(A)
+    delta = torch.zeros((5, 5, 5), device="cuda")
+    delta[2, 2, 2] = 2.0
+    otf, bp = eng.gen_otf(delta), eng.gen_otf(delta, flip=True)
+    eng.init_single(A, E)
+    eng.run_single(E, A, otf, bp, 3)
+    eng.sync()
+    assert float((E - A0).abs().max() / A0.max()) < 5e-6
+    # Gaussian PSF: RL with a normalised PSF preserves total flux to rounding
+    psf = T(do.gaussian_psf((32, 32, 32), (3.0, 1.5, 1.5)))
+    otf, bp = eng.gen_otf(psf), eng.gen_otf(psf, flip=True)
+    eng.init_single(A, E)
+    eng.run_single(E, A, otf, bp, 5)
+    eng.sync()
+    flux_in, flux_out = dev.sum_f64(A), dev.sum_f64(E)
+    assert abs(flux_out - flux_in) / flux_in < 1e-4
+    assert float(E.min()) >= 0.01
+    first = E.clone()
+    eng.init_single(A, E)
+    eng.run_single(E, A, otf, bp, 5)
+    eng.sync()
+    assert torch.equal(first, E)  # bitwise reproducible run to run
+    eng.close()

@@ -1,0 +1,211 @@
+"""GPU parity of the hand-written kernels, through the mil_device.h C ABI.
+Integer / index / single-rounding float work is compared BIT-EXACT with the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import decon_oracle as do
+from oracle import reg_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    from microimagelib_amd import device
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return device
+
+
+def T(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    return np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+SIZES = [0, 1, 3, 4, 5, 63, 64, 1023, 1024, 4099, 1 << 20, (1 << 20) + 7]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_rl_ratio_bit_exact(dev, n):
+    rng = np.random.default_rng(n)
+    A = rng.uniform(0.01, 3000, n).astype(f32)
+    Tv = rng.uniform(-5, 4000, n).astype(f32)
+    if n > 4:
+        Tv[3] = 0.0  # the reference divide is unguarded: inf must propagate identically
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = do.rl_ratio(A, Tv)
+    got = dev.rl_ratio_(T(Tv), T(A)).cpu().numpy()
+    assert bits_equal(got, want)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_rl_update_bit_exact(dev, n):
+    rng = np.random.default_rng(n + 1)
+    E = rng.uniform(0.01, 3000, n).astype(f32)
+    Tv = rng.uniform(-0.5, 2.0, n).astype(f32)
+    want = do.rl_update(E, Tv)
+    got = dev.rl_update_(T(E), T(Tv)).cpu().numpy()
+    assert bits_equal(got, want)
+    assert n == 0 or got.min() >= f32(0.01)
+
+
+def test_rl_update_nan_goes_to_eps(dev):
+    """(v > eps) ? v : eps -- a NaN product collapses to eps like the reference's
+    maxvalue3Dgpukernel (include/cukernel.cuh:389), unlike np.maximum."""
+    E = np.array([1.0, np.nan, 2.0, np.inf, 5.0], dtype=f32)
+    Tv = np.array([np.nan, 1.0, 0.0, 0.0, 2.0], dtype=f32)
+    got = dev.rl_update_(T(E), T(Tv)).cpu().numpy()
+    assert bits_equal(got, np.array([0.01, 0.01, 0.01, 0.01, 10.0], dtype=f32))
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_cmul_bit_exact(dev, n):
+    rng = np.random.default_rng(n + 2)
+    a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * f32(1e3)
+    b = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    want = do.cmul(a, b)
+    got = dev.cmul_(T(a), T(b)).cpu().numpy()
+    assert bits_equal(got, want)
+
+
+def test_elementwise_misaligned_views(dev):
+    """Sub-buffers that are not 16-byte aligned take the scalar path; same bits."""
+    rng = np.random.default_rng(5)
+    n = 10007
+    E = rng.uniform(0.01, 100, n + 3).astype(f32)
+    Tv = rng.uniform(0.5, 2.0, n + 3).astype(f32)
+    dE, dT = T(E), T(Tv)
+    dev.rl_update_(dE[1:n + 1], dT[2:n + 2])
+    want = E.copy()
+    want[1:n + 1] = do.rl_update(E[1:n + 1], Tv[2:n + 2])
+    assert bits_equal(dE.cpu().numpy(), want)
+    dA = T(E)
+    dT2 = T(Tv)
+    dev.rl_ratio_(dT2[3:n + 3], dA[1:n + 1])
+    want = Tv.copy()
+    want[3:n + 3] = do.rl_ratio(E[1:n + 1], Tv[3:n + 3])
+    assert bits_equal(dT2.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 1000003])
+def test_sum_f64(dev, n):
+    rng = np.random.default_rng(n)
+    a = rng.uniform(0, 2000, n).astype(f32)
+    want = float(np.sum(a, dtype=np.float64))
+    got = dev.sum_f64(T(a))
+    assert abs(got - want) <= 1e-12 * abs(want)
+    assert dev.sum_f64(T(a)) == got  # deterministic two-stage reduction
+
+
+def test_sum_f64_empty(dev):
+    import torch
+    assert dev.sum_f64(torch.empty(0, dtype=torch.float32, device="cuda")) == 0.0
+
+
+def test_geometry_golden(dev):
+    g = np.load(os.path.join(GOLD, "geometry.npz"))
+    a = g["a"]
+    da = T(a)
+    assert bits_equal(dev.pad_stack(da, (16, 16, 16)).cpu().numpy(), g["pad_stack"])
+    assert bits_equal(dev.crop_stack(T(g["pad_stack"]), a.shape).cpu().numpy(), g["crop"])
+    assert bits_equal(dev.align_size(da, (9, 12, 16)).cpu().numpy(), g["align_grow"])
+    assert bits_equal(dev.align_size(da, (4, 7, 8)).cpu().numpy(), g["align_shrink"])
+    assert bits_equal(dev.align_size(da, (12, 5, 13)).cpu().numpy(), g["align_mixed"])
+    assert bits_equal(dev.pad_psf(da, (16, 16, 16)).cpu().numpy(), g["pad_psf"])
+    assert bits_equal(dev.flip3(da).cpu().numpy(), g["flip"])
+
+
+@pytest.mark.parametrize("shape,box", [((5, 6, 7), (8, 8, 8)), ((8, 8, 8), (8, 8, 8)), ((1, 1, 1), (16, 32, 64)),
+                                       ((9, 16, 31), (16, 16, 32)), ((64, 64, 64), (64, 128, 320))])
+def test_geometry_vs_oracle(dev, shape, box):
+    rng = np.random.default_rng(sum(shape))
+    a = rng.standard_normal(shape).astype(f32)
+    da = T(a)
+    assert bits_equal(dev.pad_stack(da, box).cpu().numpy(), do.pad_stack(a, box))
+    assert bits_equal(dev.pad_psf(da, box).cpu().numpy(), do.pad_psf(a, box))
+    assert bits_equal(dev.pad_psf(da, box, scale=0.37, flip=True).cpu().numpy(),
+                      do.pad_psf(do.flip3(a) * f32(0.37), box))
+    big = rng.standard_normal(box).astype(f32)
+    assert bits_equal(dev.crop_stack(T(big), shape).cpu().numpy(), do.crop_stack(big, shape))
+    assert bits_equal(dev.align_size(da, box).cpu().numpy(), do.align_size(a, box))
+    assert bits_equal(dev.align_size(T(big), shape).cpu().numpy(), do.align_size(big, shape))
+    assert bits_equal(dev.flip3(da).cpu().numpy(), do.flip3(a))
+
+
+def test_pad_crop_roundtrip_full_size(dev):
+    """Size-independent property at a production-like size: crop(pad(x)) == x."""
+    import torch
+    x = torch.rand((200, 300, 500), device="cuda")
+    box = tuple(do.snap_transform_size(s) for s in x.shape)
+    assert box == (256, 320, 512)
+    y = dev.crop_stack(dev.pad_stack(x, box), x.shape)
+    assert torch.equal(x, y)
+
+
+def test_rot_y90_and_projection(dev):
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((6, 9, 13)).astype(f32)  # [z][y][x]
+    da = T(a)
+    # reference rotbyyaxiskernel (include/cukernel.cuh:438-453):
+    #  +1: out[(sx-1-i), j, k] (x-fastest index k) = in(i,j,k)  -> out[z'][y][x'] with x' = k, z' = sx-1-i
+    plus = np.transpose(a, (2, 1, 0))[::-1, :, :]
+    minus = np.transpose(a, (2, 1, 0))[:, :, ::-1]
+    assert bits_equal(dev.rot_y90(da, 1).cpu().numpy(), np.ascontiguousarray(plus))
+    assert bits_equal(dev.rot_y90(da, -1).cpu().numpy(), np.ascontiguousarray(minus))
+    # +90 then -90 is the identity
+    assert bits_equal(dev.rot_y90(dev.rot_y90(da, 1), -1).cpu().numpy(), a)
+    # maxprojectionkernel (:396-418): accumulator starts at 0
+    zero = f32(0)
+    assert bits_equal(dev.max_projection(da, 1).cpu().numpy(), np.maximum(a.max(axis=0), zero))           # [y][x]
+    assert bits_equal(dev.max_projection(da, 2).cpu().numpy(), np.maximum(a.max(axis=1), zero).T.copy())  # [x][z]
+    assert bits_equal(dev.max_projection(da, 3).cpu().numpy(), np.maximum(a.max(axis=2), zero))           # [z][y]
+
+
+def test_affine_golden(dev):
+    g = np.load(os.path.join(GOLD, "affine.npz"))
+    src, tgt = T(g["src"]), T(g["tgt"])
+    for i, m in enumerate(g["mats"]):
+        got = dev.affine_resample(src, m, g["tgt"].shape).cpu().numpy()
+        assert bits_equal(got, g["resampled"][i]), f"matrix {i}"
+        ss, st = dev.corr_sums(tgt, src, m)
+        want_ss, want_st = g["corr_sums"][i]
+        assert abs(ss - want_ss) <= 1e-12 * max(abs(want_ss), 1e-30), f"matrix {i}"
+        assert abs(st - want_st) <= 1e-11 * max(abs(want_ss), 1e-30), f"matrix {i}"
+    assert g["corr_sums"][2][0] == 0.0  # the all-out-of-bounds matrix
+    got = dev.affine_resample(src, g["resize_matrix"], g["resized"].shape).cpu().numpy()
+    assert bits_equal(got, g["resized"])
+
+
+def test_affine_identity_is_exact_copy(dev):
+    """Sample points are texel centres: the identity matrix reproduces the input."""
+    import torch
+    x = torch.rand((40, 70, 130), device="cuda")
+    ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=f32)
+    assert torch.equal(dev.affine_resample(x, ident, x.shape), x)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_affine_random_matrices_vs_oracle(dev, seed):
+    rng = np.random.default_rng(100 + seed)
+    src = rng.standard_normal((17, 23, 70)).astype(f32)
+    tgt = rng.standard_normal((19, 21, 66)).astype(f32)
+    m = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=f32) + rng.normal(0, 0.08, 12).astype(f32)
+    m[[3, 7, 11]] = rng.uniform(-4, 4, 3).astype(f32)
+    got = dev.affine_resample(T(src), m, tgt.shape).cpu().numpy()
+    assert bits_equal(got, ro.affine_transform(src, m, tgt.shape))
+    ss, st = dev.corr_sums(T(tgt), T(src), m)
+    wss, wst = ro.corr_sums(tgt, src, m)
+    assert abs(ss - wss) <= 1e-12 * wss and abs(st - wst) <= 1e-11 * wss

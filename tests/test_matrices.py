@@ -1,0 +1,82 @@
+"""Host-side registration helpers of the product (no GPU) vs the oracle and golden tables."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import reg_oracle as ro
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f32 = np.float32
+
+
+def fp(a):
+    from microimagelib_amd import _lib
+    return a.ctypes.data_as(_lib.c_float_p)
+
+
+@pytest.fixture(scope="module")
+def tables():
+    return np.load(os.path.join(ROOT, "tests", "golden", "tables.npz"))
+
+
+def test_p2matrix_roundtrip(lib):
+    rng = np.random.default_rng(0)
+    p = rng.normal(0, 1, 12).astype(f32)
+    m = np.zeros(12, dtype=f32)
+    lib.mil_p2matrix(fp(m), fp(p))
+    want = ro.p2matrix(np.concatenate([[0], p]).astype(f32))
+    assert np.array_equal(m, want)
+    back = np.zeros(12, dtype=f32)
+    lib.mil_matrix2p(fp(back), fp(m))
+    assert np.array_equal(back, p)
+    assert np.array_equal(ro.matrix2p(m)[1:], p)
+
+
+def test_matrixmultiply_table(lib, tables):
+    for a, b, want in zip(tables["mm_a"], tables["mm_b"], tables["mm_out"]):
+        out = np.zeros(12, dtype=f32)
+        lib.mil_matrixmultiply(fp(out), fp(np.ascontiguousarray(a)), fp(np.ascontiguousarray(b)))
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_matrixmultiply_allows_aliasing(lib):
+    a = np.arange(12, dtype=f32) * f32(0.1) + f32(1)
+    want = ro.matrixmultiply(a, a)
+    out = a.copy()
+    lib.mil_matrixmultiply(fp(out), fp(out), fp(out))
+    assert np.array_equal(out, want)
+
+
+def test_dof9tomatrix_table(lib, tables):
+    for p, dof, want in zip(tables["p9"], tables["dof"], tables["m9"]):
+        out = np.zeros(12, dtype=f32)
+        lib.mil_dof9tomatrix(fp(out), fp(np.ascontiguousarray(p[1:])), int(dof))
+        # cosf/sinf may differ by 1 ulp between libm and NumPy's SIMD kernels
+        assert np.max(np.abs(out - want)) <= 4e-7 * max(1.0, float(np.max(np.abs(want))))
+
+
+def test_dof9_unused_parameters_take_defaults(lib):
+    p = np.array([1, 2, 3, 40, 50, 60, 7, 8, 9], dtype=f32)
+    out = np.zeros(12, dtype=f32)
+    lib.mil_dof9tomatrix(fp(out), fp(p), 3)
+    assert np.array_equal(out, np.array([1, 0, 0, 1, 0, 1, 0, 2, 0, 0, 1, 3], dtype=f32))
+    lib.mil_dof9tomatrix(fp(out), fp(p), 7)  # one common scale
+    q = p.copy()
+    q[7] = q[8] = 7
+    ref = np.zeros(12, dtype=f32)
+    lib.mil_dof9tomatrix(fp(ref), fp(q), 9)
+    assert np.array_equal(out, ref)
+
+
+def test_rot2matrix_table(lib, tables):
+    for axis, want in zip((1, 2, 3), tables["rot"]):
+        out = np.zeros(12, dtype=f32)
+        lib.mil_rot2matrix(fp(out), float(f32(0.7)), 50, 36, 20, axis)
+        assert np.max(np.abs(out - want)) <= 1e-5
+
+
+def test_checkmatrix_table(lib, tables):
+    for m, want in zip(tables["check_in"], tables["check_out"]):
+        m = np.ascontiguousarray(m, dtype=f32)
+        assert bool(lib.checkmatrix(fp(m), 50, 36, 20)) == bool(want)
