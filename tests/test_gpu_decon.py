@@ -201,14 +201,16 @@ def test_full_size_properties(dev):
     eng.run_single(E, A, otf, bp, 3)
     eng.sync()
     assert float((E - A0).abs().max() / A0.max()) < 5e-6
-    # Gaussian PSF: RL with a normalised PSF preserves total flux to rounding
-    psf = T(do.gaussian_psf((32, 32, 32), (3.0, 1.5, 1.5)))
+    # Gaussian PSF with ODD extents (so the flipped PSF is the exact adjoint): RL with a normalised
+    # PSF preserves total flux to rounding.  (With even extents the reference's flip is one voxel off
+    # the adjoint and flux drifts by ~1e-3 per iteration on noise -- reference behaviour, kept.)
+    psf = T(do.gaussian_psf((31, 31, 31), (3.0, 1.5, 1.5)))
     otf, bp = eng.gen_otf(psf), eng.gen_otf(psf, flip=True)
     eng.init_single(A, E)
     eng.run_single(E, A, otf, bp, 5)
     eng.sync()
     flux_in, flux_out = dev.sum_f64(A), dev.sum_f64(E)
-    assert abs(flux_out - flux_in) / flux_in < 1e-4
+    assert abs(flux_out - flux_in) / flux_in < 1e-5
     assert float(E.min()) >= 0.01
     first = E.clone()
     eng.init_single(A, E)
