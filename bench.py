@@ -78,7 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--backend", choices=["auto", "rocfft", "fused"], default="auto",
+                    help="transform backend of the RL engine (auto = fused LDS-tiled kernels on power-of-two boxes)")
     args = ap.parse_args()
 
     import torch
@@ -113,7 +115,8 @@ def main():
     R = 4 * n_real
     C = 8 * SHAPE[0] * SHAPE[1] * (SHAPE[2] // 2 + 1)
 
-    eng = mdev.DeconEngine(SHAPE)
+    eng = mdev.DeconEngine(SHAPE, backend={"auto": 0, "rocfft": 1, "fused": 2}[args.backend])
+    fused = eng.backend == mdev.DeconEngine.FUSED
     otf_a = eng.gen_otf(psf_a)
     bp_a = eng.gen_otf(psf_a, flip=True)
     A = img_a.clone()
@@ -162,13 +165,35 @@ def main():
     result = None
     if rank == 0:
         value = world * args.steps / elapsed
-        upd_avg_ms = upd_ms / max(upd_n, 1)
-        achieved = 3 * R / (upd_avg_ms * 1e-3) / 1e9 if upd_n else None
+        # Kernel families timed with HIP events on the engine's stream inside the timed region, with the
+        # ALGORITHMIC bytes one launch must move (R = real volume, C = half spectrum [nz][ny][nx/2+1] complex64;
+        # DESIGN.md "Kernels").  Fused backend: every family is one hand-written kernel.
+        if fused:
+            fam = {
+                "x_update (x^-1, E=max(E*T,0.01), x fused)": (upd_ms, upd_n, 2 * C + 2 * R),
+                "x_ratio (x^-1, T=A/T, x fused)": (rat_ms, rat_n, 2 * C + R),
+                "z_conv (z, *OTF, z^-1 fused)": (cm_ms, cm_n, 3 * C),
+                "y_pass (in-place column transform)": (fft_ms, fft_n, 2 * C),
+            }
+            iter_bytes = 18 * C + 3 * R
+        else:
+            fam = {
+                "rl_update (E = max(E*T, 0.01), fused multiply+clamp)": (upd_ms, upd_n, 3 * R),
+                "rl_ratio (T = A/T)": (rat_ms, rat_n, 3 * R),
+                "cmul_otf (S *= OTF)": (cm_ms, cm_n, 3 * C),
+                "rocfft_execute (library 3-D real transform, 3-4 kernels)": (fft_ms, fft_n, R + C),
+            }
+            iter_bytes = 4 * (R + C) + 2 * 3 * C + 3 * R + 3 * R
+        own = {k: v for k, v in fam.items() if not k.startswith("rocfft")}
+        dom = max(own, key=lambda k: own[k][0])  # our kernel with the largest share of the timed region
+        dom_ms, dom_n, dom_bytes = own[dom]
+        dom_avg_ms = dom_ms / max(dom_n, 1)
+        achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_n else None
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("rl_update_bytes_per_launch")
+                traffic = json.load(open(tfile)).get("fused" if fused else "rocfft", {}).get(dom.split(" ")[0])
             except Exception:
                 traffic = None
         result = {
@@ -187,35 +212,31 @@ def main():
             "config": {
                 "workload": "deconSingleView 512x512x256 float32, RL iterations, 1 MI355X (BASELINE.json configs[1])",
                 "psf": "64x64x64 anisotropic Gaussian, matched back projector",
+                "backend": "fused" if fused else "rocfft",
                 "volumes_per_gpu": 1,
                 "sharding": "one time-point volume per GPU, no data-path collective; XY-MIP gather over RCCL after the timed region",
             },
             "roofline": {
-                "kernel": "rl_update (E = max(E*T, 0.01), fused multiply+clamp)",
+                "kernel": dom,
                 "bound": "hbm",
                 "achieved": round(achieved, 1) if achieved else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": 3 * R,
-                "avg_launch_ms": round(upd_avg_ms, 5),
-                "launches": int(upd_n),
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "avg_launch_ms": round(dom_avg_ms, 5),
+                "launches": int(dom_n),
             },
             "extra": {
-                "kernel_ms_per_launch": {
-                    "rl_update": round(upd_ms / max(upd_n, 1), 5),
-                    "rl_ratio": round(rat_ms / max(rat_n, 1), 5),
-                    "cmul_otf": round(cm_ms / max(cm_n, 1), 5),
-                    "rocfft_execute": round(fft_ms / max(fft_n, 1), 5),
+                "kernel_families": {
+                    k: {"ms_per_launch": round(ms / max(n, 1), 5), "launches": int(n), "algorithmic_bytes": b,
+                        "hbm_gbs": round(b / (ms / max(n, 1) * 1e-3) / 1e9, 1) if n and ms > 0 else None,
+                        "share_of_step": round(ms / (1e3 * elapsed), 4)}
+                    for k, (ms, n, b) in fam.items()
                 },
-                "hbm_gbs": {
-                    "rl_ratio": round(3 * R / (rat_ms / max(rat_n, 1) * 1e-3) / 1e9, 1) if rat_n else None,
-                    "cmul_otf": round(3 * C / (cm_ms / max(cm_n, 1) * 1e-3) / 1e9, 1) if cm_n else None,
-                },
-                "iteration_algorithmic_bytes": 4 * (R + C) + 2 * 3 * C + 3 * R + 3 * R,
-                "iteration_hbm_roofline_frac": round((4 * (R + C) + 6 * C + 6 * R) / (elapsed / args.steps) / 1e9
-                                                     / HBM_PEAK_GBS, 4),
+                "iteration_algorithmic_bytes": iter_bytes,
+                "iteration_hbm_roofline_frac": round(iter_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "mip_checksum": mip_checksum,
             },
         }

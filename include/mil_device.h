@@ -45,12 +45,30 @@ int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, 
 
 /* ---- deconvolution engine -------------------------------------------------- */
 typedef struct mil_decon mil_decon;
-/* FFT box (nx,ny,nz): rocFFT plans + scratch allocated once (replaces the per-call
+/* Transform backends of the engine.  FUSED: hand-written LDS-tiled transforms with the OTF
+ * product, RL ratio and estimate update fused in (power-of-two boxes, 16..1024, x <= 2048);
+ * ROCFFT: rocFFT plans + separate element-wise kernels (any box).  AUTO picks FUSED when the
+ * box allows it.  OTF / spectrum buffers are opaque: `mil_decon_spectrum_count` complex64
+ * elements, layout private to the backend (mil_decon_otf_to_natural converts). */
+#define MIL_BACKEND_AUTO 0
+#define MIL_BACKEND_ROCFFT 1
+#define MIL_BACKEND_FUSED 2
+/* FFT box (nx,ny,nz): plans / tables + scratch allocated once (replaces the per-call
  * cufftPlan3d / cudaMalloc of decon_*_OTF1, src/api_subfunc.cu:3376-3396). */
 int mil_decon_create(mil_decon **out, int nx, int ny, int nz, void *stream);
+int mil_decon_create_backend(mil_decon **out, int nx, int ny, int nz, void *stream, int backend);
 void mil_decon_destroy(mil_decon *e);
+int mil_decon_backend(const mil_decon *e);
 size_t mil_decon_real_count(const mil_decon *e);
 size_t mil_decon_spectrum_count(const mil_decon *e);
+/* d_out = C2R( R2C(d_in) * otf ), unnormalised: cufftExecR2C + multicomplex3Dgpu + cufftExecC2R,
+ * src/api_subfunc.cu:3406-3408 */
+int mil_decon_convolve(mil_decon *e, float *d_out, const float *d_in, const void *d_otf);
+/* engine OTF -> natural [nz][ny][nx/2+1] complex64 (the cufftExecR2C output order, :3298-3299) */
+int mil_decon_otf_to_natural(mil_decon *e, void *d_natural, const void *d_otf);
+/* host only: freq_of_pos[p] = frequency index held at position p after the in-place
+ * mixed-radix (8,..,8,{2,4}) forward transform of length n (power of two) */
+int mil_fft_digit_reversal(int n, unsigned short *freq_of_pos);
 /* genOTFgpu :3269 (flip != 0 applies flipgpu first: matched back projector) */
 int mil_decon_gen_otf(mil_decon *e, void *d_otf, const float *d_psf, int px, int py, int pz, int flip);
 int mil_decon_init_single(mil_decon *e, float *d_A, float *d_E, int const_init);             /* :3380-3388 */
@@ -62,7 +80,8 @@ int mil_decon_run_dual(mil_decon *e, float *d_E, const float *d_A, const float *
                        const void *d_otf2, const void *d_otf_bp1, const void *d_otf_bp2, int iters);
 int mil_decon_sync(mil_decon *e);
 /* HIP-event timers bracketing kernel families on the engine's stream.
- * which: 0 rl_update, 1 rl_ratio, 2 cmul, 3 rocFFT executes. */
+ * which (ROCFFT backend): 0 rl_update, 1 rl_ratio, 2 cmul, 3 rocFFT executes;
+ * which (FUSED backend):  0 x pass + estimate update, 1 x pass + ratio, 2 z convolution, 3 y passes. */
 int mil_decon_timer_enable(mil_decon *e, int which, int enable);
 int mil_decon_timer_read(mil_decon *e, int which, double *total_ms, size_t *launches); /* syncs, then resets */
 

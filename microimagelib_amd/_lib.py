@@ -65,7 +65,12 @@ SIGNATURES = {
     "mil_rot_y90": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "mil_max_projection": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "mil_decon_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mil_decon_create_backend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mil_decon_destroy": (None, [C.c_void_p]),
+    "mil_decon_backend": (C.c_int, [C.c_void_p]),
+    "mil_decon_convolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mil_decon_otf_to_natural": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mil_fft_digit_reversal": (C.c_int, [C.c_int, C.POINTER(C.c_ushort)]),
     "mil_decon_real_count": (C.c_size_t, [C.c_void_p]),
     "mil_decon_spectrum_count": (C.c_size_t, [C.c_void_p]),
     "mil_decon_gen_otf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -40,7 +40,8 @@ Geometry make_geometry(const unsigned int *imSize, const unsigned int *psfSize) 
     g.n_im = (size_t)g.im.count();
     g.n_psf = (size_t)g.psf.count();
     g.n_box = (size_t)g.box.count();
-    g.n_spec = (size_t)(g.box.nx / 2 + 1) * g.box.ny * g.box.nz;
+    // memory estimate only; buffers are sized by DeconEngine::spectrum_count()
+    g.n_spec = (size_t)(g.box.nx / 2 + 16) * g.box.ny * g.box.nz;
     g.padded = g.box != g.im;
     return g;
 }
@@ -132,7 +133,8 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         DeconEngine eng(g.box, nullptr);
         hipStream_t s = eng.stream();
         DeviceBuffer<float> dA(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
-        DeviceBuffer<float2> dOtf(g.n_spec), dOtfBp(g.n_spec);
+        const size_t n_spec = eng.spectrum_count();  // backend-private OTF size
+        DeviceBuffer<float2> dOtf(n_spec), dOtfBp(n_spec);
         deconRecords[2] = free_mb();
 
         make_otfs(eng, dOtf, dOtfBp, dPsf, h_psf, h_psf_bp, flagUnmatch, g);
@@ -189,7 +191,8 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         DeconEngine eng(g.box, nullptr);
         hipStream_t s = eng.stream();
         DeviceBuffer<float> dA(g.n_box), dB(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
-        DeviceBuffer<float2> dOtf1(g.n_spec), dOtf2(g.n_spec), dOtfBp1(g.n_spec), dOtfBp2(g.n_spec);
+        const size_t n_spec = eng.spectrum_count();  // backend-private OTF size
+        DeviceBuffer<float2> dOtf1(n_spec), dOtf2(n_spec), dOtfBp1(n_spec), dOtfBp2(n_spec);
         deconRecords[2] = free_mb();
 
         make_otfs(eng, dOtf1, dOtfBp1, dPsf, h_psf1, h_psf_bp1, flagUnmatch, g);  // reference :522-534

@@ -11,7 +11,7 @@ using namespace mil;
 
 struct mil_decon {
     DeconEngine engine;
-    mil_decon(Dims box, hipStream_t s) : engine(box, s) {}
+    mil_decon(Dims box, hipStream_t s, int backend) : engine(box, s, backend) {}
 };
 
 namespace {
@@ -96,11 +96,29 @@ int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, 
 }
 
 int mil_decon_create(mil_decon **out, int nx, int ny, int nz, void *stream) {
+    return mil_decon_create_backend(out, nx, ny, nz, stream, MIL_BACKEND_AUTO);
+}
+int mil_decon_create_backend(mil_decon **out, int nx, int ny, int nz, void *stream, int backend) {
     *out = nullptr;
     return guarded("mil_decon_create", [&] {
-        *out = new mil_decon(dims3(nx, ny, nz), as_stream(stream));
+        *out = new mil_decon(dims3(nx, ny, nz), as_stream(stream), backend);
         return 0;
     });
+}
+int mil_decon_backend(const mil_decon *e) { return e->engine.backend(); }
+int mil_decon_convolve(mil_decon *e, float *d_out, const float *d_in, const void *d_otf) {
+    return guarded("mil_decon_convolve", [&] { e->engine.convolve(d_out, d_in, (const float2 *)d_otf); return 0; });
+}
+int mil_decon_otf_to_natural(mil_decon *e, void *d_natural, const void *d_otf) {
+    return guarded("mil_decon_otf_to_natural", [&] {
+        e->engine.otf_to_natural((float2 *)d_natural, (const float2 *)d_otf);
+        return 0;
+    });
+}
+int mil_fft_digit_reversal(int n, unsigned short *freq_of_pos) {
+    if (n < 1 || n > 65536 || (n & (n - 1))) return -1;
+    fx::digit_reversal_freq(n, freq_of_pos);
+    return 0;
 }
 void mil_decon_destroy(mil_decon *e) { delete e; }
 size_t mil_decon_real_count(const mil_decon *e) { return e->engine.real_count(); }

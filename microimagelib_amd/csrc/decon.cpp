@@ -1,5 +1,6 @@
 #include "decon.h"
 
+#include <cstring>
 #include <mutex>
 
 namespace mil {
@@ -118,20 +119,38 @@ KernelTimer::~KernelTimer() {
 // ---------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------
-DeconEngine::DeconEngine(Dims fft_box, hipStream_t stream) : box_(fft_box), stream_(stream) {
+DeconEngine::DeconEngine(Dims fft_box, hipStream_t stream, int backend) : box_(fft_box), stream_(stream) {
     if (box_.nx <= 0 || box_.ny <= 0 || box_.nz <= 0) throw Error(-1, "DeconEngine: empty FFT box");
     if (box_.nx % 2) throw Error(-1, "DeconEngine: FFT box x extent must be even");
+    if (backend == kBackendAuto) {
+        const char *env = getenv("MIL_FFT_BACKEND");
+        if (env && !strcmp(env, "rocfft")) backend = kBackendRocfft;
+        else if (env && !strcmp(env, "fused")) backend = kBackendFused;
+        else backend = fx::ConvPlan::supported(box_) ? kBackendFused : kBackendRocfft;
+    }
+    if (backend != kBackendRocfft && backend != kBackendFused) throw Error(-1, "DeconEngine: unknown backend");
+    if (backend == kBackendFused && !fx::ConvPlan::supported(box_))
+        throw Error(-1, "DeconEngine: the fused backend needs a power-of-two box (16..1024, x up to 2048)");
     if (!stream_) {
         MIL_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         own_stream_ = true;
     }
-    T_.alloc(real_count());
-    S_.alloc(spectrum_count());
-    fft_ = new Fft3D(box_, stream_);
+    try {
+        if (backend == kBackendFused) plan_ = new fx::ConvPlan(box_);
+        else fft_ = new Fft3D(box_, stream_);
+        T_.alloc(real_count());
+        S_.alloc(spectrum_count());
+    } catch (...) {
+        delete plan_;
+        delete fft_;
+        if (own_stream_) (void)hipStreamDestroy(stream_);
+        throw;
+    }
 }
 
 DeconEngine::~DeconEngine() {
     delete fft_;
+    delete plan_;
     if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -162,7 +181,33 @@ void DeconEngine::gen_otf(float2 *d_otf, const float *d_psf, Dims P, bool flip, 
         k::pad_psf(T_.get(), aligned.get(), box_, box_, 1.0f, false, stream_);
         MIL_HIP(hipStreamSynchronize(stream_));  // temporaries die at scope exit
     }
-    fft_->r2c(T_.get(), d_otf);  // :3298-3299
+    if (plan_) {  // same forward transforms as the RL loop -> same private ordering
+        plan_->x_pass(fx::kXForward, S_.get(), T_.get(), nullptr, nullptr, 0.f, stream_);
+        plan_->y_pass(S_.get(), false, stream_);
+        plan_->z_forward_to_otf(S_.get(), d_otf, stream_);
+    } else {
+        fft_->r2c(T_.get(), d_otf);  // :3298-3299
+    }
+}
+
+void DeconEngine::convolve(float *out, const float *in, const float2 *otf) {
+    if (plan_) {
+        plan_->x_pass(fx::kXForward, S_.get(), in, nullptr, nullptr, 0.f, stream_);
+        plan_->y_pass(S_.get(), false, stream_);
+        plan_->z_conv(S_.get(), otf, stream_);
+        plan_->y_pass(S_.get(), true, stream_);
+        plan_->x_pass(fx::kXInverse, S_.get(), nullptr, out, nullptr, 0.f, stream_);
+    } else {
+        if (in != T_.get()) MIL_HIP(hipMemcpyAsync(T_.get(), in, real_count() * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+        fft_->r2c(T_.get(), S_.get());
+        k::cmul_inplace(S_.get(), otf, spectrum_count(), stream_);
+        fft_->c2r(S_.get(), out);
+    }
+}
+
+void DeconEngine::otf_to_natural(float2 *natural, const float2 *otf) {
+    if (plan_) plan_->otf_to_natural(natural, otf, stream_);
+    else MIL_HIP(hipMemcpyAsync(natural, otf, spectrum_count() * sizeof(float2), hipMemcpyDeviceToDevice, stream_));
 }
 
 void DeconEngine::init_single(float *A, float *E, bool const_init) {
@@ -189,7 +234,46 @@ void DeconEngine::init_dual(float *A, float *B, float *E, bool const_init) {
     }
 }
 
+// Fused backend: the estimate's x-spectrum is carried from one view update to the next, so a
+// view update is  y, z-conv(OTF), y^-1, x^-1 | ratio | x, y, z-conv(OTF_bp), y^-1, x^-1 | update | x.
+void DeconEngine::run_fused(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp,
+                            int views, int iters) {
+    if (iters <= 0) return;
+    float2 *S = S_.get();
+    plan_->x_pass(fx::kXForward, S, E, nullptr, nullptr, 0.f, stream_);
+    for (int it = 0; it < iters; ++it) {
+        for (int v = 0; v < views; ++v) {
+            const bool last = (it == iters - 1) && (v == views - 1);
+            for (int half = 0; half < 2; ++half) {
+                timers[kTimeFft].begin(stream_);
+                plan_->y_pass(S, false, stream_);
+                timers[kTimeFft].end(stream_);
+                timers[kTimeCmul].begin(stream_);
+                plan_->z_conv(S, half == 0 ? otf[v] : otf_bp[v], stream_);  // :3406-3408 / :3411-3413
+                timers[kTimeCmul].end(stream_);
+                timers[kTimeFft].begin(stream_);
+                plan_->y_pass(S, true, stream_);
+                timers[kTimeFft].end(stream_);
+                if (half == 0) {
+                    timers[kTimeRatio].begin(stream_);
+                    plan_->x_pass(fx::kXRatio, S, nullptr, nullptr, M[v], 0.f, stream_);  // :3409
+                    timers[kTimeRatio].end(stream_);
+                } else {
+                    timers[kTimeUpdate].begin(stream_);
+                    plan_->x_pass(last ? fx::kXUpdateLast : fx::kXUpdate, S, nullptr, E, nullptr, kSmallValue,
+                                  stream_);  // :3414-3415
+                    timers[kTimeUpdate].end(stream_);
+                }
+            }
+        }
+    }
+}
+
 void DeconEngine::view_update(float *E, const float *M, const float2 *otf, const float2 *otf_bp) {
+    if (plan_) {
+        run_fused(E, &M, &otf, &otf_bp, 1, 1);
+        return;
+    }
     const size_t n = real_count(), ns = spectrum_count();
     float *T = T_.get();
     float2 *S = S_.get();
@@ -220,11 +304,21 @@ void DeconEngine::view_update(float *E, const float *M, const float2 *otf, const
 }
 
 void DeconEngine::run_single(float *E, const float *A, const float2 *otf, const float2 *otf_bp, int iters) {
+    if (plan_) {
+        run_fused(E, &A, &otf, &otf_bp, 1, iters);
+        return;
+    }
     for (int it = 0; it < iters; ++it) view_update(E, A, otf, otf_bp);
 }
 
 void DeconEngine::run_dual(float *E, const float *A, const float *B, const float2 *otf1, const float2 *otf2,
                            const float2 *otf_bp1, const float2 *otf_bp2, int iters) {
+    if (plan_) {
+        const float *M[2] = {A, B};
+        const float2 *o[2] = {otf1, otf2}, *ob[2] = {otf_bp1, otf_bp2};
+        run_fused(E, M, o, ob, 2, iters);
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         view_update(E, A, otf1, otf_bp1);  // :3636-3646
         view_update(E, B, otf2, otf_bp2);  // :3649-3659

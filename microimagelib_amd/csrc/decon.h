@@ -1,16 +1,21 @@
 // Device-resident Richardson-Lucy engine (single- and dual-view) for MI355X.
 //
-// One engine = one FFT box on one GPU: rocFFT real 3-D plans created once, the work
-// buffer, the scratch volume T and the scratch half-spectrum S allocated once, one HIP
-// stream.  The RL loop enqueues 8 operations per view update and never synchronises
-// with the host (the reference issues cudaThreadSynchronize after every kernel,
-// src/api_subfunc.cu:248 etc.).
+// One engine = one FFT box on one GPU, one HIP stream, scratch allocated once.  Two
+// transform backends behind the same interface:
+//   kBackendFused   power-of-two boxes: our own LDS-tiled transforms with the OTF product,
+//                   the RL ratio and the estimate update fused in (fftconv.h); 8 launches
+//                   per view update; spectra / OTFs in a private layout.
+//   kBackendRocfft  any box: rocFFT real 3-D plans + the element-wise kernels of kernels.hip;
+//                   spectra in rocFFT's natural [nz][ny][nx/2+1] layout.
+// Neither path synchronises with the host inside the RL loop (the reference issues
+// cudaThreadSynchronize after every kernel, src/api_subfunc.cu:248 etc.).
 #pragma once
 
 #include <rocfft/rocfft.h>
 
 #include <vector>
 
+#include "fftconv.h"
 #include "kernels.h"
 
 namespace mil {
@@ -48,16 +53,23 @@ struct KernelTimer {  // HIP-event bracket around one kernel family, on the engi
 
 class DeconEngine {
 public:
+    // Timer families.  rocFFT backend: rl_update, rl_ratio, cmul, rocFFT executes.
+    // Fused backend: x pass with update, x pass with ratio, z convolution, y passes.
     enum Timed { kTimeUpdate = 0, kTimeRatio = 1, kTimeCmul = 2, kTimeFft = 3, kTimedCount = 4 };
+    enum Backend { kBackendAuto = 0, kBackendRocfft = 1, kBackendFused = 2 };
 
-    DeconEngine(Dims fft_box, hipStream_t stream /* nullptr: engine-owned stream */);
+    // backend kBackendAuto: fused when the box allows it (env MIL_FFT_BACKEND=rocfft|fused overrides).
+    DeconEngine(Dims fft_box, hipStream_t stream /* nullptr: engine-owned stream */, int backend = kBackendAuto);
     ~DeconEngine();
     DeconEngine(const DeconEngine &) = delete;
     DeconEngine &operator=(const DeconEngine &) = delete;
 
     Dims box() const { return box_; }
     size_t real_count() const { return (size_t)box_.count(); }
-    size_t spectrum_count() const { return (size_t)(box_.nx / 2 + 1) * box_.ny * box_.nz; }
+    int backend() const { return plan_ ? kBackendFused : kBackendRocfft; }
+    size_t natural_spectrum_count() const { return (size_t)(box_.nx / 2 + 1) * box_.ny * box_.nz; }
+    // complex64 elements of a spectrum / OTF buffer of this engine (layout is backend-private)
+    size_t spectrum_count() const { return plan_ ? plan_->spectrum_count() : natural_spectrum_count(); }
     hipStream_t stream() const { return stream_; }
 
     // genOTFgpu (+ flipgpu when `flip`), reference src/api_subfunc.cu:3269-3307.
@@ -70,6 +82,10 @@ public:
     void run_single(float *E, const float *A, const float2 *otf, const float2 *otf_bp, int iters);
     void run_dual(float *E, const float *A, const float *B, const float2 *otf1, const float2 *otf2,
                   const float2 *otf_bp1, const float2 *otf_bp2, int iters);
+    // out = irfftn(rfftn(in) * otf), unnormalised (= N * circular convolution); test / utility entry.
+    void convolve(float *out, const float *in, const float2 *otf);
+    // OTF of this engine -> natural rocFFT/numpy order [nz][ny][nx/2+1]
+    void otf_to_natural(float2 *natural, const float2 *otf);
     void synchronize();
 
     KernelTimer timers[kTimedCount];
@@ -79,7 +95,10 @@ private:
     Dims box_;
     hipStream_t stream_ = nullptr;
     bool own_stream_ = false;
-    Fft3D *fft_ = nullptr;
+    Fft3D *fft_ = nullptr;          // rocFFT backend
+    fx::ConvPlan *plan_ = nullptr;  // fused backend
+    void run_fused(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp, int views,
+                   int iters);
     DeviceBuffer<float> T_;
     DeviceBuffer<float2> S_;
     k::ReduceWorkspace red_;

@@ -1,0 +1,582 @@
+// LDS-tiled 3-D real FFT / fused convolution kernels for gfx950 (see fftconv.h).
+//
+// Every kernel works on a tile of N x 16 complex64 held in LDS as float2 tile[N][17]
+// (the +1 column of padding keeps both the row-wise staging and the column-wise
+// butterflies at <= 2-way bank conflicts).  A 16-complex tile row is one 128-byte line
+// of HBM: 8 lanes x float4, so a wave moves 8 lines per instruction.
+//
+// Transforms are in-place mixed-radix (8,8,..,{2,4}) Cooley-Tukey:
+//   DIF  natural order in  -> digit-reversed out   (forward y / z, inverse x)
+//   DIT  digit-reversed in -> natural order out    (inverse y / z, forward x)
+// DIT is the exact transpose of DIF, so forward-DIF followed by inverse-DIT needs no
+// reordering pass: the spectrum simply lives in digit-reversed y/z order, and the OTF is
+// produced by the same forward kernels so it is scrambled identically.
+// All transforms are unnormalised, like cuFFT / FFTW in the reference.
+#include "fftconv.h"
+
+#include <cmath>
+#include <vector>
+
+namespace mil {
+namespace fx {
+
+namespace {
+
+constexpr int kW = 16;    // tile width in complex columns (128 B)
+constexpr int kWP = 17;   // LDS row stride in float2
+constexpr int kNT = 256;  // threads per workgroup
+constexpr int kBatch = 8; // float4 loads in flight per lane while staging
+
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// tables hold w = exp(-2*pi*i*k/n); SIGN = -1 uses w, SIGN = +1 uses conj(w)
+template <int SIGN>
+__device__ __forceinline__ float2 tw_mul(float2 a, float2 w) {
+    return SIGN < 0 ? c_mul(a, w) : c_mulc(a, w);
+}
+// multiply by SIGN * i
+template <int SIGN>
+__device__ __forceinline__ float2 rot90(float2 a) {
+    return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft2(float2 *v) {
+    float2 a = v[0], b = v[1];
+    v[0] = c_add(a, b);
+    v[1] = c_sub(a, b);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3) {
+    float2 a0 = c_add(v0, v2), a1 = c_sub(v0, v2);
+    float2 a2 = c_add(v1, v3), a3 = rot90<SIGN>(c_sub(v1, v3));
+    v0 = c_add(a0, a2);
+    v2 = c_sub(a0, a2);
+    v1 = c_add(a1, a3);
+    v3 = c_sub(a1, a3);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft8(float2 *v) {
+    constexpr float h = 0.70710678118654752440f;
+    dft4<SIGN>(v[0], v[2], v[4], v[6]);  // even part, outputs E[0..3] in v0,v2,v4,v6
+    dft4<SIGN>(v[1], v[3], v[5], v[7]);  // odd part,  outputs O[0..3] in v1,v3,v5,v7
+    float2 o1 = v[3], o2 = v[5], o3 = v[7];
+    // w8^1, w8^2, w8^3 with w8 = exp(SIGN*i*pi/4)
+    if (SIGN < 0) {
+        o1 = make_float2((o1.x + o1.y) * h, (o1.y - o1.x) * h);
+        o3 = make_float2((o3.y - o3.x) * h, (-o3.y - o3.x) * h);
+    } else {
+        o1 = make_float2((o1.x - o1.y) * h, (o1.x + o1.y) * h);
+        o3 = make_float2((-o3.x - o3.y) * h, (o3.x - o3.y) * h);
+    }
+    o2 = rot90<SIGN>(o2);
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+    v[0] = c_add(e0, o0);
+    v[4] = c_sub(e0, o0);
+    v[1] = c_add(e1, o1);
+    v[5] = c_sub(e1, o1);
+    v[2] = c_add(e2, o2);
+    v[6] = c_sub(e2, o2);
+    v[3] = c_add(e3, o3);
+    v[7] = c_sub(e3, o3);
+}
+
+template <int R, int SIGN>
+__device__ __forceinline__ void dft_small(float2 *v) {
+    if (R == 8) dft8<SIGN>(v);
+    else if (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
+    else dft2<SIGN>(v);
+}
+
+// One radix-R pass over sub-transforms of length L of an N x 16 tile.
+//   DIF: y_k = w_L^(i*k) * DFT_R(x)[k]      DIT: y = DFT_R( w_L^(i*k) * x_k )
+// Lane mapping: column fastest (16 lanes), then butterfly index.
+template <int N, int R, int L, bool DIT, int SIGN>
+__device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float2 *__restrict__ tw) {
+    constexpr int M = L / R;            // butterflies per sub-transform
+    constexpr int NB = (N / R) * kW;    // butterflies in the tile
+    constexpr int TWS = N / L;          // table step: w_L = w_N^(N/L)
+#pragma unroll
+    for (int it = 0; it < (NB + kNT - 1) / kNT; ++it) {
+        const int idx = it * kNT + (int)threadIdx.x;
+        if ((NB % kNT) != 0 && idx >= NB) break;
+        const int c = idx & (kW - 1);
+        const int b = idx >> 4;
+        const int blk = b / M, i = b % M;
+        float2 *p = tile + (blk * L + i) * kWP + c;
+        float2 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = p[j * M * kWP];
+        if (DIT && M > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[k] = tw_mul<SIGN>(v[k], tw[i * k * TWS]);
+        }
+        dft_small<R, SIGN>(v);
+        if (!DIT && M > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[k] = tw_mul<SIGN>(v[k], tw[i * k * TWS]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) p[j * M * kWP] = v[j];
+    }
+}
+
+template <int L>
+struct Radix {
+    static constexpr int value = (L % 8 == 0) ? 8 : L;  // remainder 2 or 4 goes last
+};
+
+// Barrier contract: the tile must be complete (barrier done) on entry; on return every
+// stage has been followed by a barrier.
+template <int N, int L, int SIGN>
+__device__ __forceinline__ void fft_dif(float2 *tile, const float2 *tw) {
+    if constexpr (L > 1) {
+        constexpr int R = Radix<L>::value;
+        fft_stage<N, R, L, false, SIGN>(tile, tw);
+        __syncthreads();
+        fft_dif<N, L / R, SIGN>(tile, tw);
+    }
+}
+template <int N, int L, int SIGN>
+__device__ __forceinline__ void fft_dit(float2 *tile, const float2 *tw) {
+    if constexpr (L > 1) {
+        constexpr int R = Radix<L>::value;
+        fft_dit<N, L / R, SIGN>(tile, tw);
+        fft_stage<N, R, L, true, SIGN>(tile, tw);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// y pass / z convolution: N x 16 column tiles
+// ---------------------------------------------------------------------------
+enum ColMode { kColForward = 0, kColInverse = 1, kColConv = 2, kColToOtf = 3 };
+
+struct ColArgs {
+    float2 *S;             // spectrum (in place)
+    const float2 *otf;     // kColConv
+    float2 *otf_out;       // kColToOtf
+    const float2 *tw;      // exp(-2*pi*i*k/N)
+    long long row_stride;  // float2 elements between consecutive tile rows
+    long long outer_stride;  // float2 elements between tiles of consecutive outer index
+    int groups;            // xs / 16
+    int mode;
+};
+
+template <int N>
+__device__ __forceinline__ void tile_load(float2 *__restrict__ tile, const float2 *__restrict__ base, long long stride) {
+    constexpr int TOTAL = N * 8;  // float4 pieces
+#pragma unroll 1
+    for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
+        float4 v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(base + (long long)(idx >> 3) * stride + 2 * (idx & 7));
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            if (idx < TOTAL) {
+                float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
+                q[0] = make_float2(v[j].x, v[j].y);
+                q[1] = make_float2(v[j].z, v[j].w);
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void tile_store(const float2 *__restrict__ tile, float2 *__restrict__ base, long long stride) {
+    constexpr int TOTAL = N * 8;
+#pragma unroll 4
+    for (int idx = (int)threadIdx.x; idx < TOTAL; idx += kNT) {
+        const float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
+        const float2 a = q[0], b = q[1];
+        *reinterpret_cast<float4 *>(base + (long long)(idx >> 3) * stride + 2 * (idx & 7)) = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+// tile[p][c] *= otf[p][c], otf tile contiguous [N][16]
+template <int N>
+__device__ __forceinline__ void tile_mul(float2 *__restrict__ tile, const float2 *__restrict__ otf) {
+    constexpr int TOTAL = N * 8;
+#pragma unroll 1
+    for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
+        float4 v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(otf + 2 * idx);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            if (idx < TOTAL) {
+                float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
+                q[0] = c_mul(q[0], make_float2(v[j].x, v[j].y));
+                q[1] = c_mul(q[1], make_float2(v[j].z, v[j].w));
+            }
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(kNT) void col_kernel(ColArgs a) {
+    __shared__ float2 tile[N * kWP];
+    __shared__ float2 tw[N];
+    const int g = blockIdx.x % a.groups;
+    const long long outer = blockIdx.x / a.groups;
+    float2 *base = a.S + outer * a.outer_stride + (long long)g * kW;
+    for (int k = threadIdx.x; k < N; k += kNT) tw[k] = a.tw[k];
+    tile_load<N>(tile, base, a.row_stride);
+    __syncthreads();
+    if (a.mode == kColInverse) {
+        fft_dit<N, N, +1>(tile, tw);
+        tile_store<N>(tile, base, a.row_stride);
+        return;
+    }
+    fft_dif<N, N, -1>(tile, tw);
+    if (a.mode == kColForward) {
+        tile_store<N>(tile, base, a.row_stride);
+        return;
+    }
+    const long long otf_tile = (long long)blockIdx.x * N * kW;  // [outer][g][N][16]
+    if (a.mode == kColToOtf) {
+        tile_store<N>(tile, a.otf_out + otf_tile, kW);
+        return;
+    }
+    tile_mul<N>(tile, a.otf + otf_tile);
+    __syncthreads();
+    fft_dit<N, N, +1>(tile, tw);
+    tile_store<N>(tile, base, a.row_stride);
+}
+
+// ---------------------------------------------------------------------------
+// x pass: 16 rows per workgroup, tile[k][row], packed real <-> complex
+// ---------------------------------------------------------------------------
+struct XArgs {
+    float2 *S;
+    const float *rin;    // kXForward
+    float *rout;         // kXInverse output / estimate E (in-out) for the update modes
+    const float *M;      // kXRatio
+    const float2 *tw;    // exp(-2*pi*i*k/nx), k in [0, nx)
+    const unsigned short *pos;  // pos[n], n in [0, nx/2)
+    float eps;
+    int mode;
+};
+
+template <int NH>
+__global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
+    constexpr int NX = 2 * NH;
+    constexpr int XS = ((NH + 1 + kW - 1) / kW) * kW;
+    __shared__ float2 tile[(NH + 1) * kWP];
+    __shared__ float2 tw[NH];            // w_NH^k = w_NX^(2k)
+    __shared__ unsigned short pos[NH];
+    const long long row0 = (long long)blockIdx.x * kW;
+    for (int k = threadIdx.x; k < NH; k += kNT) {
+        tw[k] = a.tw[2 * k];
+        pos[k] = a.pos[k];
+    }
+    if (a.mode != kXForward) {
+        // ---- spectrum rows -> tile[k][row]
+        {
+            constexpr int TOTAL = kW * (XS / 2);
+            const float2 *src = a.S + row0 * XS;
+#pragma unroll 1
+            for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
+                float4 v[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int idx = it0 + j * kNT + (int)threadIdx.x;
+                    if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(src + 2 * idx);
+                }
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int idx = it0 + j * kNT + (int)threadIdx.x;
+                    if (idx < TOTAL) {
+                        const int row = idx / (XS / 2), k0 = 2 * (idx % (XS / 2));
+                        if (k0 <= NH) tile[k0 * kWP + row] = make_float2(v[j].x, v[j].y);
+                        if (k0 + 1 <= NH) tile[(k0 + 1) * kWP + row] = make_float2(v[j].z, v[j].w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Hermitian rows -> packed half-length complex sequence Z'
+        {
+            constexpr int TOTAL = kW * (NH / 2 + 1);
+            for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
+                const int row = idx & (kW - 1), k = idx >> 4;
+                float2 x = tile[k * kWP + row], y = tile[(NH - k) * kWP + row];
+                if (k == 0) x.y = 0.f, y.y = 0.f;  // C2R ignores the imaginary parts of DC and Nyquist
+                const float2 w = a.tw[k];
+                const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
+                const float ux = w.x * dx + w.y * dy, uy = w.x * dy - w.y * dx;
+                tile[k * kWP + row] = make_float2(sx - uy, sy + ux);
+                if (k != 0) tile[(NH - k) * kWP + row] = make_float2(sx + uy, ux - sy);
+            }
+        }
+        __syncthreads();
+        fft_dif<NH, NH, +1>(tile, tw);  // element n of z' now sits at position pos[n]
+        // ---- real-space epilogue, 4 consecutive x per lane
+        {
+            constexpr int TOTAL = kW * (NH / 2);
+            for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
+                const int row = idx / (NH / 2), q = idx % (NH / 2);
+                float2 *p0 = tile + pos[2 * q] * kWP + row, *p1 = tile + pos[2 * q + 1] * kWP + row;
+                const float2 z0 = *p0, z1 = *p1;
+                float4 t = make_float4(z0.x, z0.y, z1.x, z1.y);
+                const long long off = (row0 + row) * NX + 4 * q;
+                if (a.mode == kXInverse) {
+                    *reinterpret_cast<float4 *>(a.rout + off) = t;
+                } else if (a.mode == kXRatio) {  // div3Dkernel: T = A / T (unguarded)
+                    const float4 m = *reinterpret_cast<const float4 *>(a.M + off);
+                    *p0 = make_float2(m.x / t.x, m.y / t.y);
+                    *p1 = make_float2(m.z / t.z, m.w / t.w);
+                } else {  // multi3Dkernel + maxvalue3Dgpukernel: E = max(E * T, eps)
+                    float4 e = *reinterpret_cast<const float4 *>(a.rout + off);
+                    e.x = e.x * t.x; e.y = e.y * t.y; e.z = e.z * t.z; e.w = e.w * t.w;
+                    e.x = (e.x > a.eps) ? e.x : a.eps;
+                    e.y = (e.y > a.eps) ? e.y : a.eps;
+                    e.z = (e.z > a.eps) ? e.z : a.eps;
+                    e.w = (e.w > a.eps) ? e.w : a.eps;
+                    *reinterpret_cast<float4 *>(a.rout + off) = e;
+                    *p0 = make_float2(e.x, e.y);
+                    *p1 = make_float2(e.z, e.w);
+                }
+            }
+        }
+        if (a.mode == kXInverse || a.mode == kXUpdateLast) return;
+        __syncthreads();
+    } else {
+        // ---- real rows -> packed complex at digit-reversed positions
+        constexpr int TOTAL = kW * (NH / 2);
+        const float *src = a.rin + row0 * NX;
+#pragma unroll 1
+        for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
+            float4 v[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int idx = it0 + j * kNT + (int)threadIdx.x;
+                if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(src + 4 * idx);
+            }
+            if (it0 == 0) __syncthreads();  // pos[] staged
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int idx = it0 + j * kNT + (int)threadIdx.x;
+                if (idx < TOTAL) {
+                    const int row = idx / (NH / 2), q = idx % (NH / 2);
+                    tile[pos[2 * q] * kWP + row] = make_float2(v[j].x, v[j].y);
+                    tile[pos[2 * q + 1] * kWP + row] = make_float2(v[j].z, v[j].w);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- forward: packed complex FFT, then split into the Hermitian half spectrum
+    fft_dit<NH, NH, -1>(tile, tw);
+    {
+        constexpr int TOTAL = kW * (NH / 2 + 1);
+        for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
+            const int row = idx & (kW - 1), k = idx >> 4;
+            const float2 x = tile[k * kWP + row], y = tile[(k == 0 ? 0 : NH - k) * kWP + row];
+            const float2 w = a.tw[k];
+            const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
+            const float tx = w.x * dx - w.y * dy, ty = w.x * dy + w.y * dx;
+            tile[k * kWP + row] = make_float2(0.5f * (sx + ty), 0.5f * (sy - tx));
+            tile[(NH - k) * kWP + row] = make_float2(0.5f * (sx - ty), 0.5f * (-sy - tx));
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int TOTAL = kW * (XS / 2);
+        float2 *dst = a.S + row0 * XS;
+#pragma unroll 4
+        for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
+            const int row = idx / (XS / 2), k0 = 2 * (idx % (XS / 2));
+            float2 u = make_float2(0.f, 0.f), v = u;
+            if (k0 <= NH) u = tile[k0 * kWP + row];
+            if (k0 + 1 <= NH) v = tile[(k0 + 1) * kWP + row];
+            *reinterpret_cast<float4 *>(dst + 2 * idx) = make_float4(u.x, u.y, v.x, v.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// test aid: private OTF order -> natural order
+// ---------------------------------------------------------------------------
+__global__ void otf_to_natural_kernel(float2 *__restrict__ nat, const float2 *__restrict__ otf,
+                                      const unsigned short *__restrict__ freq_y,
+                                      const unsigned short *__restrict__ freq_z, int nxh1, int ny, int nz, int groups) {
+    // one thread per private element (ky_s, g, kz_s, c)
+    const long long total = (long long)ny * groups * nz * kW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % kW);
+        long long r = i / kW;
+        const int pz = (int)(r % nz);
+        r /= nz;
+        const int g = (int)(r % groups);
+        const int py = (int)(r / groups);
+        const int kx = g * kW + c;
+        if (kx < nxh1) nat[((long long)freq_z[pz] * ny + freq_y[py]) * nxh1 + kx] = otf[i];
+    }
+}
+
+bool pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
+
+void freq_rec(int n, int pos_base, int freq_mul, int freq_add, unsigned short *out) {
+    // position p of a length-n sub-transform holds frequency r*freq(p % m) + p / m
+    if (n == 1) {
+        out[pos_base] = (unsigned short)freq_add;
+        return;
+    }
+    const int r = (n % 8 == 0) ? 8 : n;
+    const int m = n / r;
+    for (int k2 = 0; k2 < r; ++k2) freq_rec(m, pos_base + k2 * m, freq_mul * r, freq_add + k2 * freq_mul, out);
+}
+
+template <class T>
+void upload(DeviceBuffer<T> &buf, const std::vector<T> &host) {
+    buf.alloc(host.size());
+    MIL_HIP(hipMemcpy(buf.get(), host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+}
+
+std::vector<float2> twiddles(int n) {
+    std::vector<float2> t((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)n;
+        t[(size_t)k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    return t;
+}
+
+template <int N>
+void launch_col(const ColArgs &a, long long blocks, hipStream_t s) {
+    hipLaunchKernelGGL(col_kernel<N>, dim3((unsigned)blocks), dim3(kNT), 0, s, a);
+}
+
+void dispatch_col(int n, const ColArgs &a, long long blocks, hipStream_t s) {
+    if (blocks <= 0 || blocks > 0x7fffffffLL) throw Error(-1, "fused FFT: grid out of range");
+    switch (n) {
+        case 16: launch_col<16>(a, blocks, s); break;
+        case 32: launch_col<32>(a, blocks, s); break;
+        case 64: launch_col<64>(a, blocks, s); break;
+        case 128: launch_col<128>(a, blocks, s); break;
+        case 256: launch_col<256>(a, blocks, s); break;
+        case 512: launch_col<512>(a, blocks, s); break;
+        case 1024: launch_col<1024>(a, blocks, s); break;
+        default: throw Error(-1, "fused FFT: unsupported column length");
+    }
+    MIL_HIP(hipGetLastError());
+}
+
+template <int NH>
+void launch_x(const XArgs &a, long long blocks, hipStream_t s) {
+    hipLaunchKernelGGL(x_kernel<NH>, dim3((unsigned)blocks), dim3(kNT), 0, s, a);
+}
+
+void dispatch_x(int nh, const XArgs &a, long long blocks, hipStream_t s) {
+    if (blocks <= 0 || blocks > 0x7fffffffLL) throw Error(-1, "fused FFT: grid out of range");
+    switch (nh) {
+        case 8: launch_x<8>(a, blocks, s); break;
+        case 16: launch_x<16>(a, blocks, s); break;
+        case 32: launch_x<32>(a, blocks, s); break;
+        case 64: launch_x<64>(a, blocks, s); break;
+        case 128: launch_x<128>(a, blocks, s); break;
+        case 256: launch_x<256>(a, blocks, s); break;
+        case 512: launch_x<512>(a, blocks, s); break;
+        case 1024: launch_x<1024>(a, blocks, s); break;
+        default: throw Error(-1, "fused FFT: unsupported row length");
+    }
+    MIL_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+void digit_reversal_freq(int n, unsigned short *freq_of_pos) { freq_rec(n, 0, 1, 0, freq_of_pos); }
+
+void digit_reversal_pos(int n, unsigned short *pos_of_elem) {
+    std::vector<unsigned short> f((size_t)n);
+    digit_reversal_freq(n, f.data());
+    for (int p = 0; p < n; ++p) pos_of_elem[f[(size_t)p]] = (unsigned short)p;
+}
+
+bool ConvPlan::supported(Dims b) {
+    return pow2(b.nx) && pow2(b.ny) && pow2(b.nz) && b.nx >= 16 && b.nx <= 2048 && b.ny >= 16 && b.ny <= 1024 &&
+           b.nz >= 16 && b.nz <= 1024;
+}
+
+ConvPlan::ConvPlan(Dims box) : box_(box) {
+    if (!supported(box)) throw Error(-1, "ConvPlan: box is not a supported power-of-two size");
+    const int nx = (int)box.nx, ny = (int)box.ny, nz = (int)box.nz, nh = nx / 2;
+    xs_ = ((nh + 1 + kW - 1) / kW) * kW;
+    upload(tw_x_, twiddles(nx));
+    upload(tw_y_, twiddles(ny));
+    upload(tw_z_, twiddles(nz));
+    std::vector<unsigned short> p((size_t)nh), fy((size_t)ny), fz((size_t)nz);
+    digit_reversal_pos(nh, p.data());
+    digit_reversal_freq(ny, fy.data());
+    digit_reversal_freq(nz, fz.data());
+    upload(pos_x_, p);
+    upload(freq_y_, fy);
+    upload(freq_z_, fz);
+}
+
+void ConvPlan::x_pass(XMode mode, float2 *S, const float *rin, float *rout, const float *M, float eps,
+                      hipStream_t s) const {
+    if (!S || (mode == kXForward && !rin) || (mode != kXForward && mode != kXRatio && !rout) || (mode == kXRatio && !M))
+        throw Error(-1, "x_pass: missing operand");
+    XArgs a;
+    a.S = S; a.rin = rin; a.rout = rout; a.M = M;
+    a.tw = tw_x_.get(); a.pos = pos_x_.get(); a.eps = eps; a.mode = (int)mode;
+    dispatch_x((int)box_.nx / 2, a, box_.ny * box_.nz / kW, s);
+}
+
+void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s) const {
+    ColArgs a;
+    a.S = S; a.otf = nullptr; a.otf_out = nullptr; a.tw = tw_y_.get();
+    a.row_stride = xs_;
+    a.outer_stride = (long long)box_.ny * xs_;
+    a.groups = xs_ / kW;
+    a.mode = inverse ? kColInverse : kColForward;
+    dispatch_col((int)box_.ny, a, (long long)a.groups * box_.nz, s);
+}
+
+void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s) const {
+    ColArgs a;
+    a.S = S; a.otf = otf; a.otf_out = nullptr; a.tw = tw_z_.get();
+    a.row_stride = (long long)box_.ny * xs_;
+    a.outer_stride = xs_;
+    a.groups = xs_ / kW;
+    a.mode = kColConv;
+    dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
+}
+
+void ConvPlan::z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) const {
+    ColArgs a;
+    a.S = const_cast<float2 *>(S); a.otf = nullptr; a.otf_out = otf; a.tw = tw_z_.get();
+    a.row_stride = (long long)box_.ny * xs_;
+    a.outer_stride = xs_;
+    a.groups = xs_ / kW;
+    a.mode = kColToOtf;
+    dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
+}
+
+void ConvPlan::otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const {
+    const int nxh1 = (int)box_.nx / 2 + 1;
+    hipLaunchKernelGGL(otf_to_natural_kernel, dim3(2048), dim3(256), 0, s, natural, otf, freq_y_.get(), freq_z_.get(),
+                       nxh1, (int)box_.ny, (int)box_.nz, xs_ / kW);
+    MIL_HIP(hipGetLastError());
+}
+
+}  // namespace fx
+}  // namespace mil

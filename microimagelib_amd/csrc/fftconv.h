@@ -1,0 +1,67 @@
+// Fused 3-D real convolution for the Richardson-Lucy loop, hand-written for gfx950.
+//
+// The reference runs every view update as  cufftExecR2C -> multicomplex3Dgpu -> cufftExecC2R ->
+// div3Dgpu -> cufftExecR2C -> multicomplex3Dgpu -> cufftExecC2R -> multi3Dgpu -> maxvalue3Dgpu
+// (src/api_subfunc.cu:3404-3416): 4 library FFTs (3-4 kernels each) + 5 element-wise passes.
+// Here the transforms are our own LDS-tiled kernels so the element-wise work rides inside them:
+//
+//   x pass   rows of the volume; packed real<->complex transform; the RL ratio / estimate update
+//            sits between the inverse and the next forward x transform of the SAME rows
+//   y pass   128-byte column tiles, in place
+//   z conv   forward z transform, complex OTF product, inverse z transform in one kernel, in place
+//
+// One view update = 8 launches moving 18 C' + 3 R bytes instead of ~26 C + 12 R (C' = padded
+// half spectrum, R = real volume).  Spectra live in a PRIVATE layout (y and z in the digit-reversed
+// order the in-place transforms leave them in, x padded to a multiple of 16 columns, OTFs tiled per
+// z-conv workgroup); nothing outside this module depends on it.  Power-of-two boxes only
+// (16..1024 per axis, x up to 2048); other boxes use the rocFFT path in decon.cpp.
+#pragma once
+
+#include "mil_common.h"
+
+namespace mil {
+namespace fx {
+
+enum XMode {
+    kXForward = 0,     // real rows -> spectrum rows
+    kXInverse = 1,     // spectrum rows -> real rows (unnormalised)
+    kXRatio = 2,       // spectrum -> T' ; T = M / T' ; T -> spectrum         (div3Dgpu fused)
+    kXUpdate = 3,      // spectrum -> T' ; E = max(E*T', eps) ; E -> spectrum  (multi3Dgpu + maxvalue3Dgpu fused)
+    kXUpdateLast = 4,  // as kXUpdate without the trailing forward transform
+};
+
+class ConvPlan {
+public:
+    static bool supported(Dims box);
+    explicit ConvPlan(Dims box);
+    Dims box() const { return box_; }
+    int xs() const { return xs_; }  // padded spectral x extent (complex columns)
+    size_t spectrum_count() const { return (size_t)xs_ * box_.ny * box_.nz; }
+
+    // x pass over all ny*nz rows.  S: private spectrum.  Arguments by mode:
+    //   kXForward     rin (real in)                      -> S
+    //   kXInverse     S                                  -> rout (real out)
+    //   kXRatio       S, M = measured image              -> S
+    //   kXUpdate(Last) S, rout = estimate E (in and out) -> S (not for Last)
+    void x_pass(XMode mode, float2 *S, const float *rin, float *rout, const float *M, float eps, hipStream_t s) const;
+    void y_pass(float2 *S, bool inverse, hipStream_t s) const;
+    // S <- inverse_z( forward_z(S) * otf ), otf in the tiled private order written by z_forward_to_otf.
+    void z_conv(float2 *S, const float2 *otf, hipStream_t s) const;
+    void z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) const;
+    // test aid: private OTF order -> natural [nz][ny][nx/2+1] (rocFFT / numpy rfftn order)
+    void otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const;
+
+private:
+    Dims box_;
+    int xs_ = 0;
+    DeviceBuffer<float2> tw_x_, tw_y_, tw_z_;   // exp(-2*pi*i*k/n), k in [0, n)
+    DeviceBuffer<unsigned short> pos_x_;        // position of element n after digit reversal, n in [0, nx/2)
+    DeviceBuffer<unsigned short> freq_y_, freq_z_;  // frequency held at scrambled position p
+};
+
+// Host-side tables (also used by the CPU tests through the C ABI).
+void digit_reversal_freq(int n, unsigned short *freq_of_pos);  // freq[p]
+void digit_reversal_pos(int n, unsigned short *pos_of_elem);   // pos[k], inverse of freq
+
+}  // namespace fx
+}  // namespace mil

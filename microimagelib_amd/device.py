@@ -141,8 +141,9 @@ class DeconEngine:
     """RL engine for one FFT box (shape ``(nz, ny, nx)``) on the current device."""
 
     TIMER_UPDATE, TIMER_RATIO, TIMER_CMUL, TIMER_FFT = 0, 1, 2, 3
+    AUTO, ROCFFT, FUSED = 0, 1, 2
 
-    def __init__(self, box_shape, stream=None):
+    def __init__(self, box_shape, stream=None, backend=0):
         self._lib = _lib.load()
         self.box_shape = tuple(int(s) for s in box_shape)
         nz, ny, nx = self.box_shape
@@ -150,9 +151,12 @@ class DeconEngine:
         # The engine runs on its own (non-default) HIP stream; `_enter` orders it after whatever
         # the caller enqueued on torch's current stream, `sync` makes results visible to the host.
         self.stream = stream if stream is not None else torch.cuda.Stream()
-        _check(self._lib.mil_decon_create(C.byref(h), nx, ny, nz, int(self.stream.cuda_stream)), "mil_decon_create")
+        _check(self._lib.mil_decon_create_backend(C.byref(h), nx, ny, nz, int(self.stream.cuda_stream), int(backend)),
+               "mil_decon_create_backend")
         self._h = h
-        self.spectrum_shape = (nz, ny, nx // 2 + 1)
+        self.backend = int(self._lib.mil_decon_backend(h))
+        self.natural_spectrum_shape = (nz, ny, nx // 2 + 1)
+        self.spectrum_count = int(self._lib.mil_decon_spectrum_count(h))  # opaque, backend-private layout
 
     def _enter(self):
         cur = torch.cuda.current_stream()
@@ -171,11 +175,25 @@ class DeconEngine:
             pass
 
     def gen_otf(self, psf: torch.Tensor, flip=False) -> torch.Tensor:
-        otf = torch.empty(self.spectrum_shape, dtype=torch.complex64, device=psf.device)
+        otf = torch.empty(self.spectrum_count, dtype=torch.complex64, device=psf.device)
         px, py, pz = _dims(psf)
         self._enter()
         _check(self._lib.mil_decon_gen_otf(self._h, _ptr(otf), _ptr(psf), px, py, pz, int(flip)), "mil_decon_gen_otf")
         return otf
+
+    def otf_to_natural(self, otf: torch.Tensor) -> torch.Tensor:
+        """Engine-private OTF -> [nz][ny][nx/2+1] complex64 (numpy rfftn order)."""
+        nat = torch.empty(self.natural_spectrum_shape, dtype=torch.complex64, device=otf.device)
+        self._enter()
+        _check(self._lib.mil_decon_otf_to_natural(self._h, _ptr(nat), _ptr(otf)), "mil_decon_otf_to_natural")
+        return nat
+
+    def convolve(self, vol: torch.Tensor, otf: torch.Tensor) -> torch.Tensor:
+        """Unnormalised circular convolution C2R(R2C(vol) * otf)."""
+        out = torch.empty_like(vol)
+        self._enter()
+        _check(self._lib.mil_decon_convolve(self._h, _ptr(out), _ptr(vol), _ptr(otf)), "mil_decon_convolve")
+        return out
 
     def init_single(self, A, E, const_init=False):
         self._enter()

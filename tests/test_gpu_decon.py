@@ -87,7 +87,7 @@ def test_golden_otf(dev, tag):
     eng = dev.DeconEngine(tuple(int(v) for v in g["box"]))
     psf = T(g["psf"])
     for flip, key in ((False, "otf"), (True, "otf_flipped")):
-        got = eng.gen_otf(psf, flip=flip)
+        got = eng.otf_to_natural(eng.gen_otf(psf, flip=flip))
         eng.sync()
         got = got.cpu().numpy()
         scale = float(np.max(np.abs(g[key])))
@@ -155,8 +155,9 @@ def test_constant_init_scale_cancels(api):
 
 
 # ---------------------------------------------------------------- oracle, mid size, engine path
+@pytest.mark.parametrize("backend", [1, 2], ids=["rocfft", "fused"])
 @pytest.mark.parametrize("dual", [False, True])
-def test_engine_vs_oracle_128(dev, dual):
+def test_engine_vs_oracle_128(dev, dual, backend):
     """Config 1 of BASELINE.json (128^3, 10 iterations) through the device-resident engine."""
     import torch
     shape = (128, 128, 128)
@@ -164,7 +165,7 @@ def test_engine_vs_oracle_128(dev, dual):
     psf_b = do.gaussian_psf((32, 32, 32), (1.5, 1.5, 3.0))
     img_a = do.synthetic_view(shape, psf_a, seed=0, noise_seed=1)
     img_b = do.synthetic_view(shape, psf_b, seed=0, noise_seed=2)
-    eng = dev.DeconEngine(shape)
+    eng = dev.DeconEngine(shape, backend=backend)
     A, B = T(img_a), T(img_b)
     E = torch.empty_like(A)
     otf_a, bp_a = eng.gen_otf(T(psf_a)), eng.gen_otf(T(psf_a), flip=True)
