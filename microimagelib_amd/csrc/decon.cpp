@@ -140,6 +140,8 @@ DeconEngine::DeconEngine(Dims fft_box, hipStream_t stream, int backend) : box_(f
         else fft_ = new Fft3D(box_, stream_);
         T_.alloc(real_count());
         S_.alloc(spectrum_count());
+        // fused backend: the x pass never writes the padding columns of S; zero once, they stay zero
+        MIL_HIP(hipMemsetAsync(S_.get(), 0, spectrum_count() * sizeof(float2), stream_));
     } catch (...) {
         delete plan_;
         delete fft_;
@@ -240,28 +242,34 @@ void DeconEngine::run_fused(float *E, const float *const *M, const float2 *const
                             int views, int iters) {
     if (iters <= 0) return;
     float2 *S = S_.get();
-    plan_->x_pass(fx::kXForward, S, E, nullptr, nullptr, 0.f, stream_);
+    // x and y kernels walk the volume in z order; each one runs opposite to its predecessor so that it
+    // starts on the slabs written last (Infinity Cache hits instead of HBM reads).  `dir` is the
+    // direction of the most recent z-ordered kernel.
+    static const bool pingpong = !(getenv("MIL_FX_PINGPONG") && !strcmp(getenv("MIL_FX_PINGPONG"), "0"));
+    bool dir = false;
+    auto next_dir = [&] { dir = pingpong ? !dir : false; return dir; };
+    plan_->x_pass(fx::kXForward, S, E, nullptr, nullptr, 0.f, stream_, dir);
     for (int it = 0; it < iters; ++it) {
         for (int v = 0; v < views; ++v) {
             const bool last = (it == iters - 1) && (v == views - 1);
             for (int half = 0; half < 2; ++half) {
                 timers[kTimeFft].begin(stream_);
-                plan_->y_pass(S, false, stream_);
+                plan_->y_pass(S, false, stream_, next_dir());
                 timers[kTimeFft].end(stream_);
                 timers[kTimeCmul].begin(stream_);
-                plan_->z_conv(S, half == 0 ? otf[v] : otf_bp[v], stream_);  // :3406-3408 / :3411-3413
+                plan_->z_conv(S, half == 0 ? otf[v] : otf_bp[v], stream_, false);  // :3406-3408 / :3411-3413
                 timers[kTimeCmul].end(stream_);
                 timers[kTimeFft].begin(stream_);
-                plan_->y_pass(S, true, stream_);
+                plan_->y_pass(S, true, stream_, dir);  // z_conv touched every slab: keep the direction
                 timers[kTimeFft].end(stream_);
                 if (half == 0) {
                     timers[kTimeRatio].begin(stream_);
-                    plan_->x_pass(fx::kXRatio, S, nullptr, nullptr, M[v], 0.f, stream_);  // :3409
+                    plan_->x_pass(fx::kXRatio, S, nullptr, nullptr, M[v], 0.f, stream_, next_dir());  // :3409
                     timers[kTimeRatio].end(stream_);
                 } else {
                     timers[kTimeUpdate].begin(stream_);
                     plan_->x_pass(last ? fx::kXUpdateLast : fx::kXUpdate, S, nullptr, E, nullptr, kSmallValue,
-                                  stream_);  // :3414-3415
+                                  stream_, next_dir());  // :3414-3415
                     timers[kTimeUpdate].end(stream_);
                 }
             }

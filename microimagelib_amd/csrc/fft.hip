@@ -15,6 +15,7 @@
 #include "fftconv.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace mil {
@@ -99,22 +100,23 @@ __device__ __forceinline__ void dft_small(float2 *v) {
 // One radix-R pass over sub-transforms of length L of an N x 16 tile.
 //   DIF: y_k = w_L^(i*k) * DFT_R(x)[k]      DIT: y = DFT_R( w_L^(i*k) * x_k )
 // Lane mapping: column fastest (16 lanes), then butterfly index.
-template <int N, int R, int L, bool DIT, int SIGN>
+template <int N, int R, int L, bool DIT, int SIGN, int W = kW>
 __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float2 *__restrict__ tw) {
+    constexpr int WP = W + 1;
     constexpr int M = L / R;            // butterflies per sub-transform
-    constexpr int NB = (N / R) * kW;    // butterflies in the tile
+    constexpr int NB = (N / R) * W;     // butterflies in the tile
     constexpr int TWS = N / L;          // table step: w_L = w_N^(N/L)
 #pragma unroll
     for (int it = 0; it < (NB + kNT - 1) / kNT; ++it) {
         const int idx = it * kNT + (int)threadIdx.x;
         if ((NB % kNT) != 0 && idx >= NB) break;
-        const int c = idx & (kW - 1);
-        const int b = idx >> 4;
+        const int c = idx % W;
+        const int b = idx / W;
         const int blk = b / M, i = b % M;
-        float2 *p = tile + (blk * L + i) * kWP + c;
+        float2 *p = tile + (blk * L + i) * WP + c;
         float2 v[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = p[j * M * kWP];
+        for (int j = 0; j < R; ++j) v[j] = p[j * M * WP];
         if (DIT && M > 1) {
 #pragma unroll
             for (int k = 1; k < R; ++k) v[k] = tw_mul<SIGN>(v[k], tw[i * k * TWS]);
@@ -125,7 +127,7 @@ __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float
             for (int k = 1; k < R; ++k) v[k] = tw_mul<SIGN>(v[k], tw[i * k * TWS]);
         }
 #pragma unroll
-        for (int j = 0; j < R; ++j) p[j * M * kWP] = v[j];
+        for (int j = 0; j < R; ++j) p[j * M * WP] = v[j];
     }
 }
 
@@ -136,21 +138,21 @@ struct Radix {
 
 // Barrier contract: the tile must be complete (barrier done) on entry; on return every
 // stage has been followed by a barrier.
-template <int N, int L, int SIGN>
+template <int N, int L, int SIGN, int W = kW>
 __device__ __forceinline__ void fft_dif(float2 *tile, const float2 *tw) {
     if constexpr (L > 1) {
         constexpr int R = Radix<L>::value;
-        fft_stage<N, R, L, false, SIGN>(tile, tw);
+        fft_stage<N, R, L, false, SIGN, W>(tile, tw);
         __syncthreads();
-        fft_dif<N, L / R, SIGN>(tile, tw);
+        fft_dif<N, L / R, SIGN, W>(tile, tw);
     }
 }
-template <int N, int L, int SIGN>
+template <int N, int L, int SIGN, int W = kW>
 __device__ __forceinline__ void fft_dit(float2 *tile, const float2 *tw) {
     if constexpr (L > 1) {
         constexpr int R = Radix<L>::value;
-        fft_dit<N, L / R, SIGN>(tile, tw);
-        fft_stage<N, R, L, true, SIGN>(tile, tw);
+        fft_dit<N, L / R, SIGN, W>(tile, tw);
+        fft_stage<N, R, L, true, SIGN, W>(tile, tw);
         __syncthreads();
     }
 }
@@ -169,6 +171,7 @@ struct ColArgs {
     long long outer_stride;  // float2 elements between tiles of consecutive outer index
     int groups;            // xs / 16
     int mode;
+    int reverse;           // walk the tiles last-to-first (ping-pong with the previous kernel: Infinity Cache reuse)
 };
 
 template <int N>
@@ -233,8 +236,9 @@ template <int N>
 __global__ __launch_bounds__(kNT) void col_kernel(ColArgs a) {
     __shared__ float2 tile[N * kWP];
     __shared__ float2 tw[N];
-    const int g = blockIdx.x % a.groups;
-    const long long outer = blockIdx.x / a.groups;
+    const unsigned bid = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int g = bid % a.groups;
+    const long long outer = bid / a.groups;
     float2 *base = a.S + outer * a.outer_stride + (long long)g * kW;
     for (int k = threadIdx.x; k < N; k += kNT) tw[k] = a.tw[k];
     tile_load<N>(tile, base, a.row_stride);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(kNT) void col_kernel(ColArgs a) {
         tile_store<N>(tile, base, a.row_stride);
         return;
     }
-    const long long otf_tile = (long long)blockIdx.x * N * kW;  // [outer][g][N][16]
+    const long long otf_tile = (long long)bid * N * kW;  // [outer][g][N][16]
     if (a.mode == kColToOtf) {
         tile_store<N>(tile, a.otf_out + otf_tile, kW);
         return;
@@ -271,74 +275,78 @@ struct XArgs {
     const float2 *tw;    // exp(-2*pi*i*k/nx), k in [0, nx)
     const unsigned short *pos;  // pos[n], n in [0, nx/2)
     float eps;
-    int mode;
+    int reverse;
+    int ablate;  // timing experiments only (MIL_FX_ABLATE): 1 skip x^-1 FFT, 2 skip x FFT
 };
 
-template <int NH>
+// RB rows per workgroup; LDS tile[k][row] with row stride RB + 1
+template <int NH, int MODE, int RB>
 __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
     constexpr int NX = 2 * NH;
     constexpr int XS = ((NH + 1 + kW - 1) / kW) * kW;
-    __shared__ float2 tile[(NH + 1) * kWP];
+    constexpr int WP = RB + 1;
+    __shared__ float2 tile[NH * WP];
     __shared__ float2 tw[NH];            // w_NH^k = w_NX^(2k)
     __shared__ unsigned short pos[NH];
-    const long long row0 = (long long)blockIdx.x * kW;
+    const unsigned bid = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const long long row0 = (long long)bid * RB;
     for (int k = threadIdx.x; k < NH; k += kNT) {
         tw[k] = a.tw[2 * k];
         pos[k] = a.pos[k];
     }
-    if (a.mode != kXForward) {
-        // ---- spectrum rows -> tile[k][row]
+    if constexpr (MODE != kXForward) {
+        // ---- spectrum rows -> packed half-length complex sequence Z' in tile[k][row].
+        // Spectrum columns are stored in mirrored pairs: column 2j = X[j], column 2j+1 = X[NH-j]
+        // (j < NH/2), column NH = X[NH/2]; one float4 is exactly the pair the Hermitian fold needs.
         {
-            constexpr int TOTAL = kW * (XS / 2);
+            constexpr int TOTAL = RB * (NH / 2);
             const float2 *src = a.S + row0 * XS;
 #pragma unroll 1
             for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
                 float4 v[kBatch];
+                float2 w[kBatch];
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     const int idx = it0 + j * kNT + (int)threadIdx.x;
-                    if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(src + 2 * idx);
+                    if (idx < TOTAL) {
+                        const int row = idx / (NH / 2), k = idx % (NH / 2);
+                        v[j] = *reinterpret_cast<const float4 *>(src + (long long)row * XS + 2 * k);
+                        w[j] = a.tw[k];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     const int idx = it0 + j * kNT + (int)threadIdx.x;
                     if (idx < TOTAL) {
-                        const int row = idx / (XS / 2), k0 = 2 * (idx % (XS / 2));
-                        if (k0 <= NH) tile[k0 * kWP + row] = make_float2(v[j].x, v[j].y);
-                        if (k0 + 1 <= NH) tile[(k0 + 1) * kWP + row] = make_float2(v[j].z, v[j].w);
+                        const int row = idx / (NH / 2), k = idx % (NH / 2);
+                        float2 x = make_float2(v[j].x, v[j].y), y = make_float2(v[j].z, v[j].w);
+                        if (k == 0) x.y = 0.f, y.y = 0.f;  // C2R ignores the imaginary parts of DC and Nyquist
+                        const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
+                        const float ux = w[j].x * dx + w[j].y * dy, uy = w[j].x * dy - w[j].y * dx;
+                        tile[k * WP + row] = make_float2(sx - uy, sy + ux);
+                        if (k != 0) tile[(NH - k) * WP + row] = make_float2(sx + uy, ux - sy);
                     }
                 }
             }
-        }
-        __syncthreads();
-        // ---- Hermitian rows -> packed half-length complex sequence Z'
-        {
-            constexpr int TOTAL = kW * (NH / 2 + 1);
-            for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
-                const int row = idx & (kW - 1), k = idx >> 4;
-                float2 x = tile[k * kWP + row], y = tile[(NH - k) * kWP + row];
-                if (k == 0) x.y = 0.f, y.y = 0.f;  // C2R ignores the imaginary parts of DC and Nyquist
-                const float2 w = a.tw[k];
-                const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
-                const float ux = w.x * dx + w.y * dy, uy = w.x * dy - w.y * dx;
-                tile[k * kWP + row] = make_float2(sx - uy, sy + ux);
-                if (k != 0) tile[(NH - k) * kWP + row] = make_float2(sx + uy, ux - sy);
+            if (threadIdx.x < RB) {  // self-paired middle column: Z'[NH/2] = 2 conj(X[NH/2])
+                const float2 m = src[(long long)threadIdx.x * XS + NH];
+                tile[(NH / 2) * WP + threadIdx.x] = make_float2(2.f * m.x, -2.f * m.y);
             }
         }
         __syncthreads();
-        fft_dif<NH, NH, +1>(tile, tw);  // element n of z' now sits at position pos[n]
+        if (!(a.ablate & 1)) fft_dif<NH, NH, +1, RB>(tile, tw);  // element n of z' now sits at position pos[n]
         // ---- real-space epilogue, 4 consecutive x per lane
         {
-            constexpr int TOTAL = kW * (NH / 2);
+            constexpr int TOTAL = RB * (NH / 2);
             for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
                 const int row = idx / (NH / 2), q = idx % (NH / 2);
-                float2 *p0 = tile + pos[2 * q] * kWP + row, *p1 = tile + pos[2 * q + 1] * kWP + row;
+                float2 *p0 = tile + pos[2 * q] * WP + row, *p1 = tile + pos[2 * q + 1] * WP + row;
                 const float2 z0 = *p0, z1 = *p1;
                 float4 t = make_float4(z0.x, z0.y, z1.x, z1.y);
                 const long long off = (row0 + row) * NX + 4 * q;
-                if (a.mode == kXInverse) {
+                if (MODE == kXInverse) {
                     *reinterpret_cast<float4 *>(a.rout + off) = t;
-                } else if (a.mode == kXRatio) {  // div3Dkernel: T = A / T (unguarded)
+                } else if (MODE == kXRatio) {  // div3Dkernel: T = A / T (unguarded)
                     const float4 m = *reinterpret_cast<const float4 *>(a.M + off);
                     *p0 = make_float2(m.x / t.x, m.y / t.y);
                     *p1 = make_float2(m.z / t.z, m.w / t.w);
@@ -355,11 +363,11 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
                 }
             }
         }
-        if (a.mode == kXInverse || a.mode == kXUpdateLast) return;
+        if constexpr (MODE == kXInverse || MODE == kXUpdateLast) return;
         __syncthreads();
     } else {
         // ---- real rows -> packed complex at digit-reversed positions
-        constexpr int TOTAL = kW * (NH / 2);
+        constexpr int TOTAL = RB * (NH / 2);
         const float *src = a.rin + row0 * NX;
 #pragma unroll 1
         for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
@@ -375,38 +383,32 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
                 const int idx = it0 + j * kNT + (int)threadIdx.x;
                 if (idx < TOTAL) {
                     const int row = idx / (NH / 2), q = idx % (NH / 2);
-                    tile[pos[2 * q] * kWP + row] = make_float2(v[j].x, v[j].y);
-                    tile[pos[2 * q + 1] * kWP + row] = make_float2(v[j].z, v[j].w);
+                    tile[pos[2 * q] * WP + row] = make_float2(v[j].x, v[j].y);
+                    tile[pos[2 * q + 1] * WP + row] = make_float2(v[j].z, v[j].w);
                 }
             }
         }
         __syncthreads();
     }
     // ---- forward: packed complex FFT, then split into the Hermitian half spectrum
-    fft_dit<NH, NH, -1>(tile, tw);
+    if (!(a.ablate & 2)) fft_dit<NH, NH, -1, RB>(tile, tw);
+    // ---- split into the Hermitian half spectrum and store the mirrored pairs (X[k], X[NH-k])
     {
-        constexpr int TOTAL = kW * (NH / 2 + 1);
-        for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
-            const int row = idx & (kW - 1), k = idx >> 4;
-            const float2 x = tile[k * kWP + row], y = tile[(k == 0 ? 0 : NH - k) * kWP + row];
-            const float2 w = a.tw[k];
-            const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
-            const float tx = w.x * dx - w.y * dy, ty = w.x * dy + w.y * dx;
-            tile[k * kWP + row] = make_float2(0.5f * (sx + ty), 0.5f * (sy - tx));
-            tile[(NH - k) * kWP + row] = make_float2(0.5f * (sx - ty), 0.5f * (-sy - tx));
-        }
-    }
-    __syncthreads();
-    {
-        constexpr int TOTAL = kW * (XS / 2);
+        constexpr int TOTAL = RB * (NH / 2);
         float2 *dst = a.S + row0 * XS;
 #pragma unroll 4
         for (int idx = threadIdx.x; idx < TOTAL; idx += kNT) {
-            const int row = idx / (XS / 2), k0 = 2 * (idx % (XS / 2));
-            float2 u = make_float2(0.f, 0.f), v = u;
-            if (k0 <= NH) u = tile[k0 * kWP + row];
-            if (k0 + 1 <= NH) v = tile[(k0 + 1) * kWP + row];
-            *reinterpret_cast<float4 *>(dst + 2 * idx) = make_float4(u.x, u.y, v.x, v.y);
+            const int row = idx / (NH / 2), k = idx % (NH / 2);
+            const float2 x = tile[k * WP + row], y = tile[(k == 0 ? 0 : NH - k) * WP + row];
+            const float2 w = a.tw[k];
+            const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
+            const float tx = w.x * dx - w.y * dy, ty = w.x * dy + w.y * dx;
+            *reinterpret_cast<float4 *>(dst + (long long)row * XS + 2 * k) =
+                make_float4(0.5f * (sx + ty), 0.5f * (sy - tx), 0.5f * (sx - ty), 0.5f * (-sy - tx));
+        }
+        if (threadIdx.x < RB) {  // X[NH/2] = conj(Z[NH/2])
+            const float2 m = tile[(NH / 2) * WP + threadIdx.x];
+            dst[(long long)threadIdx.x * XS + NH] = make_float2(m.x, -m.y);
         }
     }
 }
@@ -426,8 +428,10 @@ __global__ void otf_to_natural_kernel(float2 *__restrict__ nat, const float2 *__
         r /= nz;
         const int g = (int)(r % groups);
         const int py = (int)(r / groups);
-        const int kx = g * kW + c;
-        if (kx < nxh1) nat[((long long)freq_z[pz] * ny + freq_y[py]) * nxh1 + kx] = otf[i];
+        const int col = g * kW + c, nh = nxh1 - 1;  // mirrored-pair column order of the x pass
+        if (col > nh) continue;
+        const int kx = (col == nh) ? nh / 2 : ((col & 1) ? nh - (col >> 1) : (col >> 1));
+        nat[((long long)freq_z[pz] * ny + freq_y[py]) * nxh1 + kx] = otf[i];
     }
 }
 
@@ -479,25 +483,44 @@ void dispatch_col(int n, const ColArgs &a, long long blocks, hipStream_t s) {
     MIL_HIP(hipGetLastError());
 }
 
-template <int NH>
-void launch_x(const XArgs &a, long long blocks, hipStream_t s) {
-    hipLaunchKernelGGL(x_kernel<NH>, dim3((unsigned)blocks), dim3(kNT), 0, s, a);
+template <int NH, int RB>
+void launch_x(int mode, const XArgs &a, long long rows, hipStream_t s) {
+    const dim3 grid((unsigned)(rows / RB)), block(kNT);
+    switch (mode) {
+        case kXForward: hipLaunchKernelGGL((x_kernel<NH, kXForward, RB>), grid, block, 0, s, a); break;
+        case kXInverse: hipLaunchKernelGGL((x_kernel<NH, kXInverse, RB>), grid, block, 0, s, a); break;
+        case kXRatio: hipLaunchKernelGGL((x_kernel<NH, kXRatio, RB>), grid, block, 0, s, a); break;
+        case kXUpdate: hipLaunchKernelGGL((x_kernel<NH, kXUpdate, RB>), grid, block, 0, s, a); break;
+        case kXUpdateLast: hipLaunchKernelGGL((x_kernel<NH, kXUpdateLast, RB>), grid, block, 0, s, a); break;
+        default: throw Error(-1, "fused FFT: unknown x mode");
+    }
 }
 
-void dispatch_x(int nh, const XArgs &a, long long blocks, hipStream_t s) {
-    if (blocks <= 0 || blocks > 0x7fffffffLL) throw Error(-1, "fused FFT: grid out of range");
+void dispatch_x(int nh, int rb, int mode, const XArgs &a, long long rows, hipStream_t s) {
+    if (rows <= 0 || rows % 16 || rows / 8 > 0x7fffffffLL) throw Error(-1, "fused FFT: row count out of range");
+#define MIL_X_CASE(NHV)                                              \
+    case NHV:                                                        \
+        if (rb == 8) launch_x<NHV, 8>(mode, a, rows, s);             \
+        else launch_x<NHV, 16>(mode, a, rows, s);                    \
+        break;
     switch (nh) {
-        case 8: launch_x<8>(a, blocks, s); break;
-        case 16: launch_x<16>(a, blocks, s); break;
-        case 32: launch_x<32>(a, blocks, s); break;
-        case 64: launch_x<64>(a, blocks, s); break;
-        case 128: launch_x<128>(a, blocks, s); break;
-        case 256: launch_x<256>(a, blocks, s); break;
-        case 512: launch_x<512>(a, blocks, s); break;
-        case 1024: launch_x<1024>(a, blocks, s); break;
+        MIL_X_CASE(8)
+        MIL_X_CASE(16)
+        MIL_X_CASE(32)
+        MIL_X_CASE(64)
+        MIL_X_CASE(128)
+        MIL_X_CASE(256)
+        MIL_X_CASE(512)
+        MIL_X_CASE(1024)
         default: throw Error(-1, "fused FFT: unsupported row length");
     }
+#undef MIL_X_CASE
     MIL_HIP(hipGetLastError());
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 }  // namespace
@@ -519,6 +542,8 @@ ConvPlan::ConvPlan(Dims box) : box_(box) {
     if (!supported(box)) throw Error(-1, "ConvPlan: box is not a supported power-of-two size");
     const int nx = (int)box.nx, ny = (int)box.ny, nz = (int)box.nz, nh = nx / 2;
     xs_ = ((nh + 1 + kW - 1) / kW) * kW;
+    x_rows_ = env_int("MIL_FX_XROWS", 8) == 16 ? 16 : 8;
+    ablate_ = env_int("MIL_FX_ABLATE", 0);
     upload(tw_x_, twiddles(nx));
     upload(tw_y_, twiddles(ny));
     upload(tw_z_, twiddles(nz));
@@ -532,32 +557,35 @@ ConvPlan::ConvPlan(Dims box) : box_(box) {
 }
 
 void ConvPlan::x_pass(XMode mode, float2 *S, const float *rin, float *rout, const float *M, float eps,
-                      hipStream_t s) const {
+                      hipStream_t s, bool reverse) const {
     if (!S || (mode == kXForward && !rin) || (mode != kXForward && mode != kXRatio && !rout) || (mode == kXRatio && !M))
         throw Error(-1, "x_pass: missing operand");
     XArgs a;
     a.S = S; a.rin = rin; a.rout = rout; a.M = M;
-    a.tw = tw_x_.get(); a.pos = pos_x_.get(); a.eps = eps; a.mode = (int)mode;
-    dispatch_x((int)box_.nx / 2, a, box_.ny * box_.nz / kW, s);
+    a.tw = tw_x_.get(); a.pos = pos_x_.get(); a.eps = eps; a.reverse = reverse ? 1 : 0;
+    a.ablate = ablate_;
+    dispatch_x((int)box_.nx / 2, x_rows_, (int)mode, a, box_.ny * box_.nz, s);
 }
 
-void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s) const {
+void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s, bool reverse) const {
     ColArgs a;
     a.S = S; a.otf = nullptr; a.otf_out = nullptr; a.tw = tw_y_.get();
     a.row_stride = xs_;
     a.outer_stride = (long long)box_.ny * xs_;
     a.groups = xs_ / kW;
     a.mode = inverse ? kColInverse : kColForward;
+    a.reverse = reverse ? 1 : 0;
     dispatch_col((int)box_.ny, a, (long long)a.groups * box_.nz, s);
 }
 
-void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s) const {
+void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s, bool reverse) const {
     ColArgs a;
     a.S = S; a.otf = otf; a.otf_out = nullptr; a.tw = tw_z_.get();
     a.row_stride = (long long)box_.ny * xs_;
     a.outer_stride = xs_;
     a.groups = xs_ / kW;
     a.mode = kColConv;
+    a.reverse = reverse ? 1 : 0;
     dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
 }
 
@@ -568,6 +596,7 @@ void ConvPlan::z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) con
     a.outer_stride = xs_;
     a.groups = xs_ / kW;
     a.mode = kColToOtf;
+    a.reverse = 0;
     dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
 }
 

@@ -43,10 +43,13 @@ public:
     //   kXInverse     S                                  -> rout (real out)
     //   kXRatio       S, M = measured image              -> S
     //   kXUpdate(Last) S, rout = estimate E (in and out) -> S (not for Last)
-    void x_pass(XMode mode, float2 *S, const float *rin, float *rout, const float *M, float eps, hipStream_t s) const;
-    void y_pass(float2 *S, bool inverse, hipStream_t s) const;
+    // reverse: walk the tiles last-to-first.  Alternating the direction between consecutive kernels lets
+    // each kernel start on the lines its predecessor wrote last (still in the 256 MB Infinity Cache).
+    void x_pass(XMode mode, float2 *S, const float *rin, float *rout, const float *M, float eps, hipStream_t s,
+                bool reverse = false) const;
+    void y_pass(float2 *S, bool inverse, hipStream_t s, bool reverse = false) const;
     // S <- inverse_z( forward_z(S) * otf ), otf in the tiled private order written by z_forward_to_otf.
-    void z_conv(float2 *S, const float2 *otf, hipStream_t s) const;
+    void z_conv(float2 *S, const float2 *otf, hipStream_t s, bool reverse = false) const;
     void z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) const;
     // test aid: private OTF order -> natural [nz][ny][nx/2+1] (rocFFT / numpy rfftn order)
     void otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const;
@@ -54,6 +57,8 @@ public:
 private:
     Dims box_;
     int xs_ = 0;
+    int x_rows_ = 8;   // rows per x-pass workgroup (8 or 16; MIL_FX_XROWS)
+    int ablate_ = 0;   // MIL_FX_ABLATE: timing experiments only, results are wrong when non-zero
     DeviceBuffer<float2> tw_x_, tw_y_, tw_z_;   // exp(-2*pi*i*k/n), k in [0, n)
     DeviceBuffer<unsigned short> pos_x_;        // position of element n after digit reversal, n in [0, nx/2)
     DeviceBuffer<unsigned short> freq_y_, freq_z_;  // frequency held at scrambled position p
