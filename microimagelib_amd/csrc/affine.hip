@@ -15,6 +15,9 @@
 // hit L1/L2 and HBM traffic stays ~ (target + source) bytes.
 #include "kernels.h"
 
+#include <cstdint>
+#include <cstdlib>
+
 namespace mil {
 namespace k {
 
@@ -56,6 +59,13 @@ __device__ __forceinline__ Tap make_tap(float t, int n) {
     return p;
 }
 
+// The two x taps of a row are adjacent floats except where the clamp folds them onto one edge
+// voxel, so one 8-byte gather at b = clamp(i, 0, sx-2) serves both: half the texture-address work of two
+// 4-byte gathers (the cost kernel is bound by gather issue, not by HBM).  4-byte alignment only.
+struct __attribute__((packed, aligned(4))) Pair {
+    float lo, hi;
+};
+
 __device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int sx, int sy, int sz, float tx, float ty,
                                               float tz) {
     Tap X = make_tap(tx, sx), Y = make_tap(ty, sy), Z = make_tap(tz, sz);
@@ -64,6 +74,19 @@ __device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int
     const float *p01 = src + Z.i0 * plane + Y.i1 * row;
     const float *p10 = src + Z.i1 * plane + Y.i0 * row;
     const float *p11 = src + Z.i1 * plane + Y.i1 * row;
+    if (sx >= 2) {
+        const int b = X.i0 < sx - 2 ? X.i0 : sx - 2;  // X.i0 >= 0 already
+        const bool lo0 = X.i0 == b, lo1 = X.i1 == b;
+        const Pair q00 = *reinterpret_cast<const Pair *>(p00 + b), q01 = *reinterpret_cast<const Pair *>(p01 + b);
+        const Pair q10 = *reinterpret_cast<const Pair *>(p10 + b), q11 = *reinterpret_cast<const Pair *>(p11 + b);
+        float c00 = X.w0 * (lo0 ? q00.lo : q00.hi) + X.w1 * (lo1 ? q00.lo : q00.hi);
+        float c01 = X.w0 * (lo0 ? q01.lo : q01.hi) + X.w1 * (lo1 ? q01.lo : q01.hi);
+        float c10 = X.w0 * (lo0 ? q10.lo : q10.hi) + X.w1 * (lo1 ? q10.lo : q10.hi);
+        float c11 = X.w0 * (lo0 ? q11.lo : q11.hi) + X.w1 * (lo1 ? q11.lo : q11.hi);
+        float c0 = Y.w0 * c00 + Y.w1 * c01;
+        float c1 = Y.w0 * c10 + Y.w1 * c11;
+        return Z.w0 * c0 + Z.w1 * c1;
+    }
     float c00 = X.w0 * p00[X.i0] + X.w1 * p00[X.i1];
     float c01 = X.w0 * p01[X.i0] + X.w1 * p01[X.i1];
     float c10 = X.w0 * p10[X.i0] + X.w1 * p10[X.i1];
@@ -114,6 +137,7 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
         const int z1 = (z0 + kCorrZ < a.tz) ? z0 + kCorrZ : a.tz;
         const float *tp = tgt + (size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z0);
         const size_t tstep = (size_t)a.tx * a.ty;
+#pragma unroll 4
         for (int z = z0; z < z1; ++z, tp += tstep) {
             const float iz = (float)z;
             const float tx = coord(a.m + 0, ix, iy, iz);
@@ -140,6 +164,154 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
         for (int w = 0; w < kTileY; ++w) {
             a0 += lds[w];
             a1 += lds[kTileY + w];
+        }
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        partials[b] = a0;
+        partials[nblocks + b] = a1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS-staged cost kernel.  The direct kernel above issues 8 global gathers per voxel and is bound by
+// the texture-address path (16 cycles per wave-instruction), not by HBM.  Here a workgroup owns a
+// 32 x 16 x 16 target tile, computes the exact source bounding box of the tile, stages that slab in LDS
+// with coalesced 16-byte loads, and takes the 8 taps from LDS.
+//
+// Exactness of the bounding box: coord() is a fixed sequence of float32 multiplies and adds, each
+// monotone in its operands, so t(x,y,z) is monotone along every axis and its extremes over the tile are
+// attained at the 8 corners -- evaluated with the same expression they bound every voxel's t bit-for-bit;
+// floor and the index clamp are monotone too.  A tile whose slab exceeds the LDS budget (large
+// rotations / scales) falls back to global gathers for that workgroup.
+// Per-voxel arithmetic is identical to corr_kernel, so (ss, st) differ only by float64 summation order.
+// ---------------------------------------------------------------------------
+constexpr int kLX = 32, kLY = 16, kLZ = 16;
+constexpr int kSlabFloats = 20000;  // 80,000 B -> two workgroups per CU
+
+struct SlabBox {
+    int x0, y0, z0;  // slab origin in the source (x0 a multiple of 4)
+    int bx, by, bz;  // slab extents (bx a multiple of 4)
+};
+
+__device__ __forceinline__ void axis_range(const float *r, const float *cx, const float *cy, const float *cz, int n,
+                                           int &lo, int &hi) {
+    float tmin = coord(r, cx[0], cy[0], cz[0]), tmax = tmin;
+#pragma unroll
+    for (int c = 1; c < 8; ++c) {
+        const float t = coord(r, cx[c & 1], cy[(c >> 1) & 1], cz[(c >> 2) & 1]);
+        tmin = fminf(tmin, t);
+        tmax = fmaxf(tmax, t);
+    }
+    // taps of a voxel inside the window: i = floor(t - 0.5), i + 1, both clamped to [0, n-1]
+    const float fn = (float)n;
+    const float a = fminf(fmaxf(tmin, -2.0f), fn + 2.0f), b = fminf(fmaxf(tmax, -2.0f), fn + 2.0f);
+    int i0 = (int)floorf(a - 0.5f), i1 = (int)floorf(b - 0.5f) + 1;
+    lo = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);
+    hi = i1 < 0 ? 0 : (i1 > n - 1 ? n - 1 : i1);
+}
+
+__device__ __forceinline__ float fetch_linear_slab(const float *__restrict__ slab, const SlabBox &bb, int sx, int sy,
+                                                   int sz, float tx, float ty, float tz) {
+    Tap X = make_tap(tx, sx), Y = make_tap(ty, sy), Z = make_tap(tz, sz);
+    const int row = bb.bx, plane = bb.bx * bb.by;
+    const float *p00 = slab + (Z.i0 - bb.z0) * plane + (Y.i0 - bb.y0) * row - bb.x0;
+    const float *p01 = slab + (Z.i0 - bb.z0) * plane + (Y.i1 - bb.y0) * row - bb.x0;
+    const float *p10 = slab + (Z.i1 - bb.z0) * plane + (Y.i0 - bb.y0) * row - bb.x0;
+    const float *p11 = slab + (Z.i1 - bb.z0) * plane + (Y.i1 - bb.y0) * row - bb.x0;
+    float c00 = X.w0 * p00[X.i0] + X.w1 * p00[X.i1];
+    float c01 = X.w0 * p01[X.i0] + X.w1 * p01[X.i1];
+    float c10 = X.w0 * p10[X.i0] + X.w1 * p10[X.i1];
+    float c11 = X.w0 * p11[X.i0] + X.w1 * p11[X.i1];
+    float c0 = Y.w0 * c00 + Y.w1 * c01;
+    float c1 = Y.w0 * c10 + Y.w1 * c11;
+    return Z.w0 * c0 + Z.w1 * c1;
+}
+
+constexpr int kSlabThreads = 512;  // 32 x-lanes x 16 y-rows; every thread walks the tile's 16 z
+
+__global__ __launch_bounds__(kSlabThreads) void corr_slab_kernel(const float *__restrict__ tgt,
+                                                               const float *__restrict__ src, AffineArgs a,
+                                                               double *__restrict__ partials, int nblocks) {
+    __shared__ __attribute__((aligned(16))) float slab[kSlabFloats];
+    __shared__ double red[2 * (kSlabThreads / 64)];
+    const int X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY, Z0 = blockIdx.z * kLZ;
+    const int X1 = min(X0 + kLX, a.tx) - 1, Y1 = min(Y0 + kLY, a.ty) - 1, Z1 = min(Z0 + kLZ, a.tz) - 1;
+    // ---- source bounding box of this tile (wave-uniform)
+    const float cx[2] = {(float)X0, (float)X1}, cy[2] = {(float)Y0, (float)Y1}, cz[2] = {(float)Z0, (float)Z1};
+    int xl, xh, yl, yh, zl, zh;
+    axis_range(a.m + 0, cx, cy, cz, a.sx, xl, xh);
+    axis_range(a.m + 4, cx, cy, cz, a.sy, yl, yh);
+    axis_range(a.m + 8, cx, cy, cz, a.sz, zl, zh);
+    SlabBox bb;
+    bb.x0 = xl & ~3; bb.y0 = yl; bb.z0 = zl;
+    bb.bx = ((xh - bb.x0 + 1) + 3) & ~3; bb.by = yh - yl + 1; bb.bz = zh - zl + 1;
+    const long long need = (long long)bb.bx * bb.by * bb.bz;
+    const bool staged = need <= kSlabFloats;
+    if (staged) {
+        // float4 pieces of the slab, 8 loads in flight per lane before the first LDS write
+        const int q4 = bb.bx >> 2, rows = bb.by * bb.bz, total = q4 * rows;
+        const float rq4 = 1.0f / (float)q4, rby = 1.0f / (float)bb.by;
+        constexpr int kB = 8;
+        for (int it0 = 0; it0 < total; it0 += kSlabThreads * kB) {
+            float4 v[kB];
+            int dst[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int idx = it0 + j * kSlabThreads + (int)threadIdx.x;
+                dst[j] = -1;
+                if (idx < total) {
+                    // exact small-integer division through float (all operands < 2^15)
+                    int r = (int)(((float)idx + 0.5f) * rq4);
+                    const int q = idx - r * q4;
+                    int czz = (int)(((float)r + 0.5f) * rby);
+                    const int cyy = r - czz * bb.by;
+                    v[j] = *reinterpret_cast<const float4 *>(
+                        src + ((size_t)(bb.z0 + czz) * a.sy + (size_t)(bb.y0 + cyy)) * a.sx + bb.x0 + 4 * q);
+                    dst[j] = r * bb.bx + 4 * q;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kB; ++j)
+                if (dst[j] >= 0) *reinterpret_cast<float4 *>(slab + dst[j]) = v[j];
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (kLX - 1), ly = threadIdx.x >> 5;
+    const int x = X0 + lx, y = Y0 + ly;
+    double ss = 0.0, st = 0.0;
+    if (x < a.tx && y < a.ty) {
+        const float ix = (float)x, iy = (float)y;
+        const size_t tstep = (size_t)a.tx * a.ty;
+        const float *tp = tgt + (size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * Z0);
+#pragma unroll 4
+        for (int z = Z0; z <= Z1; ++z, tp += tstep) {
+            const float iz = (float)z;
+            const float tx = coord(a.m + 0, ix, iy, iz);
+            const float ty = coord(a.m + 4, ix, iy, iz);
+            const float tz = coord(a.m + 8, ix, iy, iz);
+            float sv = 0.0f;
+            if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
+                sv = staged ? fetch_linear_slab(slab, bb, a.sx, a.sy, a.sz, tx, ty, tz)
+                            : fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
+            const float tv = *tp;
+            ss += (double)sv * (double)sv;
+            st += (double)sv * (double)tv;
+        }
+    }
+    ss = wave_sum(ss);
+    st = wave_sum(st);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = kSlabThreads / 64;
+    if (lane == 0) {
+        red[wave] = ss;
+        red[NW + wave] = st;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            a0 += red[w];
+            a1 += red[NW + w];
         }
         const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         partials[b] = a0;
@@ -206,17 +378,24 @@ CorrWorkspace::~CorrWorkspace() {
 void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
                      CorrWorkspace &ws, hipStream_t s) {
     AffineArgs a = make_args(t_dims, s_dims, m);
-    dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
+    // slab staging uses aligned float4 rows of the source; anything else takes the direct-gather kernel
+    static const bool use_slab = getenv("MIL_CORR_SLAB") && getenv("MIL_CORR_SLAB")[0] == '1';
+    const bool slab_ok = use_slab && (a.sx % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    dim3 grid = slab_ok ? dim3((a.tx + kLX - 1) / kLX, (a.ty + kLY - 1) / kLY, (a.tz + kLZ - 1) / kLZ)
+                        : dim3((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
     if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
-    double *dev_out = ws.partials.get() + 2 * nblocks;
-    hipLaunchKernelGGL(corr_kernel, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(), (int)nblocks);
+    if (slab_ok)
+        hipLaunchKernelGGL(corr_slab_kernel, grid, dim3(kSlabThreads), 0, s, target, src, a, ws.partials.get(), (int)nblocks);
+    else
+        hipLaunchKernelGGL(corr_kernel, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
+                           (int)nblocks);
     MIL_HIP(hipGetLastError());
-    hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(kFinalThreads), 0, s, ws.partials.get(), (int)nblocks, dev_out);
+    // the final pass writes (ss, st) straight into pinned host memory: no copy node, one stream sync per evaluation
+    hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(kFinalThreads), 0, s, ws.partials.get(), (int)nblocks, ws.host);
     MIL_HIP(hipGetLastError());
-    MIL_HIP(hipMemcpyAsync(ws.host, dev_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
 }
 
 void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,

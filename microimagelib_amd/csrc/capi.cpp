@@ -2,6 +2,8 @@
 #include "../../include/mil_device.h"
 
 #include <cstring>
+#include <map>
+#include <memory>
 
 #include "decon.h"
 #include "powell.h"
@@ -184,8 +186,13 @@ int mil_corr_sums(const float *d_target, const float *d_src, int tx, int ty, int
     return guarded("mil_corr_sums", [&] {
         k::Affine12 m;
         std::memcpy(m.m, m12, sizeof m.m);
-        k::CorrWorkspace ws;
-        k::corr_sums_sync(d_target, d_src, dims3(tx, ty, tz), dims3(sx, sy, sz), m, ws, as_stream(stream), &h_out[0],
+        // one workspace per (thread, device): the partials buffer and the pinned result slot are reused
+        static thread_local std::map<int, std::unique_ptr<k::CorrWorkspace>> cache;
+        int dev = 0;
+        MIL_HIP(hipGetDevice(&dev));
+        auto &ws = cache[dev];
+        if (!ws) ws.reset(new k::CorrWorkspace());
+        k::corr_sums_sync(d_target, d_src, dims3(tx, ty, tz), dims3(sx, sy, sz), m, *ws, as_stream(stream), &h_out[0],
                           &h_out[1]);
         return 0;
     });

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the registration cost kernel (mil_corr_sums) at 512x512x256."""
+import sys, time, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from microimagelib_amd import device as mdev
+
+shape = (256, 512, 512)
+g = torch.Generator(device="cuda").manual_seed(0)
+tgt = torch.rand(shape, device="cuda", generator=g)
+src = torch.rand(shape, device="cuda", generator=g)
+
+def matrix(deg, scale, shift):
+    c, s = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
+    lin = scale * np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+    centre = np.array([256.0, 256.0, 128.0])
+    t = centre - lin @ centre + np.array(shift)
+    return np.concatenate([lin, t[:, None]], axis=1).astype(np.float32).reshape(12)
+
+for name, m in (("identity", matrix(0, 1, (0, 0, 0))), ("rot3_s1.02", matrix(3, 1.02, (5, -3, 2))),
+                ("rot10", matrix(10, 1.0, (0, 0, 0))), ("rot45", matrix(45, 1.0, (0, 0, 0)))):
+    ss, st = mdev.corr_sums(tgt, src, m)
+    torch.cuda.synchronize()
+    n = 50
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = mdev.corr_sums(tgt, src, m)
+    dt = (time.perf_counter() - t0) / n
+    vox = tgt.numel()
+    print(f"{name:12s} {dt*1e3:8.3f} ms/eval  {vox/dt/1e9:8.1f} Gvoxel/s  {2*4*vox/dt/1e9:8.1f} GB/s algorithmic  ss={ss:.6e} st={st:.6e}")
