@@ -1,0 +1,216 @@
+"""Time-lapse batch: the spimFusionBatch loop sharded one volume pair per GPU.
+
+The reference processes time points strictly one after another on one device
+(src/spim_fusion_batch.cpp:613-966): resize / rotate, register view B to view A
+according to ``regMode``, joint dual-view RL, write the result, 2-D and 3-D MIPs.
+Time points are independent except in ``regMode 2`` (the starting matrix of time
+point t is a running 0.8 / 0.2 average of the earlier results, :786-808).
+
+Here: one process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests), time points dealt round-robin, OTFs computed
+once per rank and reused for all its time points.  There is NO collective on the data
+path; the only exchange is
+
+  * regMode 1: the matrix found on the test time point is broadcast from rank 0
+    (12 floats), mirroring "register one, apply to all" (:719-751);
+  * the final gather of the per-time-point XY maximum-intensity projections to rank 0.
+
+``regMode 2`` carries a loop dependence between time points and is only accepted on a
+single rank.  All volume arithmetic happens in ``libapi.so``; this module is host logic.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# --------------------------------------------------------------------------- sharding / exchange
+def shard_time_points(time_points: Sequence[int], rank: int, world: int) -> List[int]:
+    """Round-robin deal: rank r gets time_points[r], [r + world], ...  (1 volume pair per GPU at a time)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank / world size")
+    return list(time_points[rank::world])
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def broadcast_matrix(tmx: Optional[np.ndarray], src: int = 0, device="cpu", group=None) -> np.ndarray:
+    """regMode 1: every rank applies the matrix registered on the test time point (12 floats from `src`)."""
+    rank, world = _world(group)
+    t = torch.zeros(12, dtype=torch.float32, device=device)
+    if rank == src:
+        t.copy_(torch.as_tensor(np.asarray(tmx, dtype=np.float32).reshape(12)))
+    if world > 1:
+        dist.broadcast(t, src=src, group=group)
+    return t.cpu().numpy()
+
+
+def gather_mip_stack(local: Dict[int, torch.Tensor], time_points: Sequence[int], mip_shape: Tuple[int, int],
+                     device="cpu", group=None) -> Optional[torch.Tensor]:
+    """Gather per-time-point MIPs (rank-local dict t -> [H, W] float32) into a time-ordered stack on rank 0.
+
+    Every rank contributes a fixed-size slab (ceil(n / world) slots, unused slots zero) so a single
+    ``gather`` moves everything; rank 0 re-orders the slots into time order.  Returns [n, H, W] on rank 0,
+    None elsewhere."""
+    rank, world = _world(group)
+    n = len(time_points)
+    slots = (n + world - 1) // world
+    mine = shard_time_points(time_points, rank, world)
+    slab = torch.zeros((max(slots, 1),) + tuple(mip_shape), dtype=torch.float32, device=device)
+    for i, t in enumerate(mine):
+        slab[i].copy_(local[t])
+    if world == 1:
+        parts = [slab]
+    else:
+        parts = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+        dist.gather(slab, gather_list=parts, dst=0, group=group)
+        if rank != 0:
+            return None
+    out = torch.empty((n,) + tuple(mip_shape), dtype=torch.float32, device=device)
+    for r in range(world):
+        for i, t in enumerate(shard_time_points(time_points, r, world)):
+            out[list(time_points).index(t)].copy_(parts[r][i])
+    return out
+
+
+# --------------------------------------------------------------------------- registration policy
+@dataclass
+class RegPolicy:
+    """The reference's per-time-point registration logic (src/spim_fusion_batch.cpp:714-843)."""
+    reg_mode: int = 0           # 0 apply input matrix | 1 register test point, apply to all | 2 chained | 3 independent
+    reg_choice: int = 2         # reg3d regChoice for the first attempt
+    aff_method: int = 6         # batch hard-codes 6 (:557)
+    ftol: float = 1e-4
+    it_limit: int = 3000
+    cost_bar: float = 0.1       # ZNCC threshold of the retry heuristics (costValueBar)
+    i_tmx: Optional[np.ndarray] = None   # input matrix (flagiTmx)
+    test_time_point: Optional[int] = None
+    # state of regMode 2
+    weighted: Optional[np.ndarray] = field(default=None, repr=False)
+    previous: Optional[np.ndarray] = field(default=None, repr=False)
+
+
+RegFn = Callable[..., Tuple[object, np.ndarray, np.ndarray]]
+# reg_fn(target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit) -> (registered, tmx[12], records[11])
+CheckFn = Callable[[np.ndarray], bool]
+
+
+def register_pair(policy: RegPolicy, reg_fn: RegFn, check_fn: CheckFn, target, source, first: bool):
+    """One time point's registration with the reference's fall-back ladder.  Returns (registered, tmx, records)."""
+    p = policy
+    have_input = p.i_tmx is not None
+
+    def attempt(choice, tmx, use_input):
+        return reg_fn(target, source, tmx, choice, p.aff_method, use_input, p.ftol, p.it_limit)
+
+    def bad(tmx, rec):
+        return (not check_fn(tmx)) or (rec[3] < p.cost_bar)
+
+    if p.reg_mode == 0:  # regChoice forced to 0: apply the input matrix, or copy (:614-616, :717-721)
+        return attempt(0, p.i_tmx, have_input)
+    if p.reg_mode in (1, 3) or (p.reg_mode == 2 and first):
+        reg, tmx, rec = attempt(p.reg_choice, p.i_tmx, have_input)
+        if bad(tmx, rec):  # change scheme and redo (:730-735, :762-767, :815-820)
+            alt = 2 if p.reg_choice == 4 else 4
+            reg, tmx, rec = attempt(alt, None, False)
+            if bad(tmx, rec) and have_input:  # fall back to the input matrix (:736-746)
+                reg, tmx, rec = attempt(0, p.i_tmx, True)
+        if p.reg_mode == 2:
+            p.weighted = np.array(tmx, dtype=np.float32)
+            p.previous = np.array(tmx, dtype=np.float32)
+        return reg, tmx, rec
+    if p.reg_mode == 2:  # start from the running average, fall back to the previous matrix (:786-808)
+        reg, tmx, rec = attempt(2, p.weighted, True)
+        if bad(tmx, rec):
+            reg, tmx, rec = attempt(0, p.previous, True)
+        p.weighted = (0.8 * p.weighted + 0.2 * np.asarray(tmx, dtype=np.float32)).astype(np.float32)
+        p.previous = np.array(tmx, dtype=np.float32)
+        return reg, tmx, rec
+    raise ValueError(f"regMode {p.reg_mode} is not one of 0, 1, 2, 3")
+
+
+# --------------------------------------------------------------------------- the sharded loop
+def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[object, object]],
+                fuse_pair: Callable[[object, object, int], Tuple[object, torch.Tensor]],
+                policy: RegPolicy, reg_fn: RegFn, check_fn: CheckFn, mip_shape: Tuple[int, int],
+                sink: Optional[Callable[[int, object, np.ndarray, np.ndarray], None]] = None,
+                device="cpu", group=None) -> Optional[torch.Tensor]:
+    """Run the batch over this rank's share of `time_points`.
+
+    load_pair(t) -> (view A, view B) already resized / rotated; fuse_pair(A, B_registered, t) -> (decon, XY MIP);
+    sink(t, decon, tmx, reg_records) persists per-time-point outputs (rank-local, no exchange).
+    Returns the time-ordered MIP stack on rank 0."""
+    rank, world = _world(group)
+    time_points = list(time_points)
+    if policy.reg_mode == 2 and world > 1:
+        raise ValueError("regMode 2 chains the matrix from one time point to the next: run it on one rank, "
+                         "or use regMode 1 / 3 for a sharded batch")
+    if policy.reg_mode == 1:
+        # register the test time point once (rank 0), then every rank applies that matrix (:719-751)
+        tmx = None
+        if rank == 0:
+            t_test = policy.test_time_point if policy.test_time_point is not None else time_points[0]
+            a, b = load_pair(t_test)
+            _, tmx, _ = register_pair(policy, reg_fn, check_fn, a, b, first=True)
+        tmx = broadcast_matrix(tmx, 0, device=device, group=group)
+        policy = RegPolicy(reg_mode=0, reg_choice=0, aff_method=policy.aff_method, ftol=policy.ftol,
+                           it_limit=policy.it_limit, cost_bar=policy.cost_bar, i_tmx=tmx)
+    local: Dict[int, torch.Tensor] = {}
+    for i, t in enumerate(shard_time_points(time_points, rank, world)):
+        a, b = load_pair(t)
+        b_reg, tmx, rec = register_pair(policy, reg_fn, check_fn, a, b, first=(i == 0))
+        decon, mip = fuse_pair(a, b_reg, t)
+        local[t] = mip
+        if sink is not None:
+            sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
+    return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
+
+
+# --------------------------------------------------------------------------- GPU pipeline (device-resident)
+class FusionPipeline:
+    """reg3d -> decon_dualview -> XY MIP on device-resident volumes of one GPU (libapi.so kernels only)."""
+
+    def __init__(self, shape, psf_a: torch.Tensor, psf_b: torch.Tensor, iters: int, psf_a_bp: Optional[torch.Tensor] = None,
+                 psf_b_bp: Optional[torch.Tensor] = None):
+        from . import device as mdev
+        self._mdev = mdev
+        self.shape = tuple(int(s) for s in shape)
+        self.iters = int(iters)
+        self.engine = mdev.DeconEngine(self.shape)
+        # four OTFs once per rank (the reference recomputes them for every time point, src/api_decon.cpp:524-547)
+        self.otf_a = self.engine.gen_otf(psf_a)
+        self.otf_b = self.engine.gen_otf(psf_b)
+        self.bp_a = self.engine.gen_otf(psf_a_bp) if psf_a_bp is not None else self.engine.gen_otf(psf_a, flip=True)
+        self.bp_b = self.engine.gen_otf(psf_b_bp) if psf_b_bp is not None else self.engine.gen_otf(psf_b, flip=True)
+        self.estimate = torch.empty(self.shape, dtype=torch.float32, device=psf_a.device)
+
+    def reg_fn(self, target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
+        """reg3d on device volumes: regChoice 0 (apply / copy) and 2 (affine); the coarse pre-registrations
+        (1, 3, 4) are not on the hot path and fall back to plain affine here."""
+        method = 0 if reg_choice == 0 else aff_method
+        return self._mdev.reg3d_affine(target, source, aff_method=method, i_tmx=i_tmx, flag_tmx=bool(input_tmx),
+                                       ftol=ftol, it_limit=it_limit)
+
+    def check_fn(self, tmx) -> bool:
+        from . import api
+        nz, ny, nx = self.shape
+        return api.checkmatrix(tmx, nx, ny, nz)
+
+    def fuse_pair(self, a: torch.Tensor, b_reg: torch.Tensor, t: int):
+        A, B = a.clone(), b_reg.clone()  # the engine clamps its inputs in place
+        self.engine.init_dual(A, B, self.estimate)
+        self.engine.run_dual(self.estimate, A, B, self.otf_a, self.otf_b, self.bp_a, self.bp_b, self.iters)
+        self.engine.sync()
+        mip = self._mdev.max_projection(self.estimate, 1)
+        return self.estimate, mip
+
+    def close(self):
+        self.engine.close()

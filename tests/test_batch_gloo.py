@@ -1,0 +1,164 @@
+"""Host logic of the sharded time-lapse batch (microimagelib_amd/batch.py) on CPU:
+world_size-2 ``gloo`` runs of the sharding, the regMode-1 matrix broadcast and the MIP gather,
+plus the reference's registration fall-back ladder (src/spim_fusion_batch.cpp:714-843).
+No volume arithmetic happens here: the compute callbacks are stand-ins, the GPU pipeline
+behind them is covered by the -m gpu tests."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from microimagelib_amd import batch
+
+MIP_SHAPE = (4, 6)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_reg(log):
+    def reg_fn(target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
+        tmx = np.zeros(12, dtype=np.float32)
+        if reg_choice == 0:
+            if input_tmx:
+                tmx[:] = np.asarray(i_tmx, dtype=np.float32)
+            else:
+                tmx[[0, 5, 10]] = 1
+        else:  # "registration": a matrix that encodes the time point it was computed on
+            tmx[[0, 5, 10]] = 1
+            tmx[3] = float(target)
+        rec = np.zeros(11, dtype=np.float32)
+        rec[3] = 0.9
+        log.append((int(target), int(reg_choice), bool(input_tmx)))
+        return source, tmx, rec
+    return reg_fn
+
+
+def _worker(rank, world, port, outdir, reg_mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tps = [3, 4, 5, 6, 7]
+        log, sunk = [], {}
+        policy = batch.RegPolicy(reg_mode=reg_mode, reg_choice=2, test_time_point=5)
+
+        def load_pair(t):
+            return t, t  # stand-in volumes: the time point itself
+
+        def fuse_pair(a, b_reg, t):
+            return None, torch.full(MIP_SHAPE, float(10 * t + 1))
+
+        def sink(t, decon, tmx, rec):
+            sunk[t] = tmx.tolist()
+
+        err = None
+        stack = None
+        try:
+            stack = batch.run_sharded(tps, load_pair, fuse_pair, policy, _fake_reg(log), lambda m: True, MIP_SHAPE,
+                                      sink=sink)
+        except ValueError as e:
+            err = str(e)
+        json.dump({"log": log, "sunk": sunk, "err": err, "stack": None if stack is None else stack[:, 0, 0].tolist(),
+                   "stack_shape": None if stack is None else list(stack.shape)},
+                  open(os.path.join(outdir, f"rank{rank}.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(tmp_path, reg_mode, world=2):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), reg_mode), nprocs=world, join=True)
+    return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+
+
+def test_shard_is_a_partition():
+    tps = list(range(1, 65))
+    for world in (1, 2, 3, 8):
+        parts = [batch.shard_time_points(tps, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == tps
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    with pytest.raises(ValueError):
+        batch.shard_time_points(tps, 2, 2)
+
+
+@pytest.mark.timeout(120)
+def test_independent_registration_two_ranks(tmp_path):
+    """regMode 3: every time point registered on the rank that owns it; MIPs gathered in time order."""
+    r0, r1 = _run(tmp_path, reg_mode=3)
+    assert sorted(int(t) for t in r0["sunk"]) == [3, 5, 7] and sorted(int(t) for t in r1["sunk"]) == [4, 6]
+    assert r1["stack"] is None
+    assert r0["stack_shape"] == [5, *MIP_SHAPE]
+    assert r0["stack"] == [31.0, 41.0, 51.0, 61.0, 71.0]
+    for r in (r0, r1):  # each owned time point registered once with regChoice 2, no input matrix
+        assert all(c == 2 and not inp for (_, c, inp) in r["log"])
+        for t, m in r["sunk"].items():
+            assert m[3] == float(t)
+
+
+@pytest.mark.timeout(120)
+def test_register_once_apply_to_all_two_ranks(tmp_path):
+    """regMode 1: rank 0 registers the test time point, the 12 floats are broadcast, every rank applies them."""
+    r0, r1 = _run(tmp_path, reg_mode=1)
+    assert r0["log"][0] == [5, 2, False]  # the registration itself, on the test time point
+    for r in (r0, r1):
+        applied = [e for e in r["log"] if e[1] == 0]
+        assert len(applied) == len(r["sunk"]) and all(inp for (_, _, inp) in applied)
+        for m in r["sunk"].values():
+            assert m[3] == 5.0 and m[0] == 1.0  # the matrix found on time point 5
+    assert r0["stack"] == [31.0, 41.0, 51.0, 61.0, 71.0]
+
+
+@pytest.mark.timeout(120)
+def test_chained_mode_refuses_to_shard(tmp_path):
+    r0, r1 = _run(tmp_path, reg_mode=2)
+    assert "regMode 2" in r0["err"] and "regMode 2" in r1["err"]
+
+
+def test_fallback_ladder_matches_reference():
+    """Low ZNCC on the first attempt -> other scheme without input matrix -> input matrix (regChoice 0)."""
+    calls = []
+
+    def reg_fn(target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
+        calls.append((reg_choice, input_tmx))
+        rec = np.zeros(11, dtype=np.float32)
+        rec[3] = 0.05 if reg_choice != 0 else 0.5
+        tmx = np.eye(3, 4, dtype=np.float32).reshape(12) if i_tmx is None else np.asarray(i_tmx, dtype=np.float32)
+        return source, tmx, rec
+
+    given = (np.eye(3, 4, dtype=np.float32) * 1.01).reshape(12)
+    pol = batch.RegPolicy(reg_mode=3, reg_choice=2, i_tmx=given)
+    _, tmx, rec = batch.register_pair(pol, reg_fn, lambda m: True, 0, 0, first=True)
+    assert calls == [(2, True), (4, False), (0, True)]
+    assert np.allclose(tmx, given) and rec[3] == 0.5
+    # regChoice 4 first -> the alternative scheme is 2
+    calls.clear()
+    batch.register_pair(batch.RegPolicy(reg_mode=3, reg_choice=4), reg_fn, lambda m: True, 0, 0, first=True)
+    assert calls == [(4, False), (2, False)]
+
+
+def test_chained_mode_running_average_single_rank():
+    """regMode 2 on one rank: matrix of time point t starts from 0.8*weighted + 0.2*previous result."""
+    starts = []
+
+    def reg_fn(target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
+        starts.append(None if i_tmx is None else float(np.asarray(i_tmx)[3]))
+        tmx = np.eye(3, 4, dtype=np.float32).reshape(12)
+        tmx[3] = float(target)  # "found" shift = time point
+        rec = np.zeros(11, dtype=np.float32)
+        rec[3] = 0.9
+        return source, tmx, rec
+
+    pol = batch.RegPolicy(reg_mode=2, reg_choice=2)
+    stack = batch.run_sharded([10, 20, 30], lambda t: (t, t), lambda a, b, t: (None, torch.zeros(MIP_SHAPE)), pol,
+                              reg_fn, lambda m: True, MIP_SHAPE)
+    assert stack.shape == (3, *MIP_SHAPE)
+    assert starts[0] is None and starts[1] == 10.0 and abs(starts[2] - (0.8 * 10 + 0.2 * 20)) < 1e-5

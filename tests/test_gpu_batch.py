@@ -1,0 +1,40 @@
+"""GPU: the device-resident batch pipeline (reg3d -> dual-view RL -> XY MIP) on one rank, checked
+against the oracle per time point."""
+import numpy as np
+import pytest
+
+from oracle import decon_oracle as do
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fusion_pipeline_single_rank():
+    import torch
+    assert torch.cuda.is_available()
+    from microimagelib_amd import batch
+
+    shape = (32, 64, 64)
+    psf_a = do.gaussian_psf((9, 9, 9), (2.0, 1.2, 1.2))
+    psf_b = do.gaussian_psf((9, 9, 9), (1.2, 1.2, 2.0))
+    views = {t: (do.synthetic_view(shape, psf_a, seed=t, noise_seed=10 + t, n_blobs=12),
+                 do.synthetic_view(shape, psf_b, seed=t, noise_seed=20 + t, n_blobs=12)) for t in (1, 2, 3)}
+    pipe = batch.FusionPipeline(shape, torch.from_numpy(psf_a).cuda(), torch.from_numpy(psf_b).cuda(), iters=4)
+    decons = {}
+
+    def load_pair(t):
+        a, b = views[t]
+        return torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+
+    def sink(t, decon, tmx, rec):
+        decons[t] = decon.cpu().numpy().copy()
+        assert np.allclose(tmx, np.eye(3, 4, dtype=np.float32).reshape(12))  # regMode 0 without matrix: copy
+
+    stack = batch.run_sharded([1, 2, 3], load_pair, pipe.fuse_pair, batch.RegPolicy(reg_mode=0), pipe.reg_fn,
+                              pipe.check_fn, (shape[1], shape[2]), sink=sink, device="cuda")
+    pipe.close()
+    assert stack.shape == (3, shape[1], shape[2])
+    for i, t in enumerate((1, 2, 3)):
+        want = do.decon_dualview(views[t][0], views[t][1], psf_a, psf_b, 4)
+        floor = float(np.mean(np.abs(want)))
+        assert float(np.max(np.abs(decons[t] - want) / np.maximum(np.abs(want), floor))) < 1e-5
+        assert np.array_equal(stack[i].cpu().numpy(), np.maximum(decons[t].max(axis=0), 0))
