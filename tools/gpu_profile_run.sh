@@ -1,13 +1,15 @@
-set -x
-mkdir -p gpurun_out/r01_fused
+# Full round evidence: GPU tests, bench (headline + extras + CPU baseline), rocprofv3 stats and PMC passes.
+#   usage (on the GPU box): bash tools/gpu_profile_run.sh <tag>
+tag=${1:-r01_fused}
+out=gpurun_out/$tag
+mkdir -p $out
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_decon.py tests/test_gpu_fft.py -x -q 2>&1 | tail -8 > gpurun_out/r01_fused/tests.log
-timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/r01_fused/bench_fused.json 2> gpurun_out/r01_fused/bench_fused.err
-timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --backend rocfft > gpurun_out/r01_fused/bench_rocfft.json 2> gpurun_out/r01_fused/bench_rocfft.err
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01_fused/stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/r01_fused/prof_stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r01_fused/pmc_fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/r01_fused/prof_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r01_fused/pmc_write -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/r01_fused/prof_write.log 2>&1
-find gpurun_out/r01_fused -name "*.csv" | xargs ls -la
-# keep the merged output small: drop per-dispatch traces > 20 MB
-find gpurun_out/r01_fused -size +20M -delete
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" > $out/tests.log
+timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-extra --backend rocfft > $out/bench_rocfft_backend.json 2> $out/bench_rocfft.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $out/prof_stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > $out/prof_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > $out/prof_write.log 2>&1
+find $out -size +20M -delete
+cat $out/tests.log $out/bench.json

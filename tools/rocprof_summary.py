@@ -18,7 +18,8 @@ import sys
 from collections import defaultdict
 
 OURS = {  # kernel-name pattern -> bench.py family key (config size 512x512x256)
-    "fused": {r"x_kernel<256>": "x", r"col_kernel<512>": "y_pass", r"col_kernel<256>": "z_conv"},
+    "fused": {r"x_kernel<256, 3,": "x_update", r"x_kernel<256, 2,": "x_ratio", r"col_kernel<512>": "y_pass",
+              r"col_kernel<256>": "z_conv"},
     "rocfft": {r"ew_inplace2_kernel<.*UpdateOp": "rl_update", r"ew_inplace2_kernel<.*RatioOp": "rl_ratio",
                r"cmul_kernel": "cmul_otf"},
 }
@@ -68,7 +69,7 @@ def main(src, dst):
                         traffic.setdefault(backend, {})[key] = v["hbm_bytes_per_launch"]
         traffic["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py at 512x512x256; "
                              "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE correction, "
-                             "MI355X_MICROARCH.md); x = mean over the x-pass modes")
+                             "MI355X_MICROARCH.md)")
         json.dump(traffic, open(tfile, "w"), indent=1)
     print("wrote", dst)
 
