@@ -132,7 +132,8 @@ def main():
     # product).  Every event is a stream marker, so bracketing all 8 launches of a step would itself cost
     # a few percent of it; the other families are timed in a second, un-clocked pass of the same K steps.
     dom_timer = mdev.DeconEngine.TIMER_FFT if fused else mdev.DeconEngine.TIMER_CMUL
-    eng.timer_enable(dom_timer, True)
+    if not os.environ.get("MIL_BENCH_NO_EVENTS"):  # diagnostic: how much the in-region markers cost
+        eng.timer_enable(dom_timer, True)
 
     def fence():
         torch.cuda.synchronize()

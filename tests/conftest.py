@@ -18,7 +18,7 @@ def _built_artifacts():
     """Build libapi.so and the oracle pieces when they are missing (CPU box).  On the GPU
     box the prebuilt files travel with the snapshot."""
     lib = os.path.join(ROOT, "microimagelib_amd", "libapi.so")
-    if not os.path.exists(lib):
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(ROOT, "microimagelib_amd", "bin", "reg3D")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "microimagelib_amd", "csrc"), "-j4"])
     ref = os.path.join(ROOT, "oracle", "_ref", "libpowell_ref.so")
     if not os.path.exists(ref) and os.path.isdir("/root/reference"):

@@ -1,7 +1,9 @@
-"""GPU end-to-end drop-in check: the REFERENCE's own command-line programs (mains compiled from
-/root/reference/src/*.cpp by oracle/Makefile, linked against our libapi.so through our
-include/libapi.h) run on TIFF files and must reproduce the oracle.  Skipped when the prebuilt
-binaries did not travel (they are built in the container that has the reference tree)."""
+"""GPU end-to-end drop-in check on TIFF files, for two sets of command-line programs:
+  reference  the REFERENCE's own mains (compiled from /root/reference/src/*.cpp by oracle/Makefile, linked against
+             our libapi.so through our include/libapi.h); skipped when the prebuilt binaries did not travel
+             (they are built in the container that has the reference tree);
+  ours       microimagelib_amd/bin/* (microimagelib_amd/cli/*.cpp, same flags).
+Both must reproduce the oracle."""
 import os
 import subprocess
 
@@ -13,12 +15,19 @@ from oracle import reg_oracle as ro
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLI = os.path.join(ROOT, "oracle", "_ref", "cli")
+DIRS = {"reference": os.path.join(ROOT, "oracle", "_ref", "cli"), "ours": os.path.join(ROOT, "microimagelib_amd", "bin")}
 
 
-def _need(name):
-    path = os.path.join(CLI, name)
+@pytest.fixture(params=["reference", "ours"])
+def which(request):
+    return request.param
+
+
+def _need(name, which):
+    path = os.path.join(DIRS[which], name)
     if not os.path.exists(path):
+        if which == "ours":
+            raise AssertionError(f"{path} missing: run make -C microimagelib_amd/csrc")
         pytest.skip(f"{path} not built (needs the reference tree at build time)")
     return path
 
@@ -28,9 +37,9 @@ def rel_err(got, want):
     return float(np.max(np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), floor)))
 
 
-def test_reference_deconSingleView_cli(tmp_path):
+def test_deconSingleView_cli(tmp_path, which):
     from microimagelib_amd import api
-    exe = _need("deconSingleView")
+    exe = _need("deconSingleView", which)
     shape = (20, 36, 50)  # box 64x64x32: pad + crop
     psf = do.gaussian_psf((9, 9, 9), (2.0, 1.2, 1.2))
     img = do.synthetic_view(shape, psf, seed=0, noise_seed=1, n_blobs=12)
@@ -46,9 +55,9 @@ def test_reference_deconSingleView_cli(tmp_path):
     assert rel_err(got, do.decon_singleview(img, psf, 6)) < 1e-5
 
 
-def test_reference_deconDualView_cli(tmp_path):
+def test_deconDualView_cli(tmp_path, which):
     from microimagelib_amd import api
-    exe = _need("deconDualView")
+    exe = _need("deconDualView", which)
     shape = (32, 64, 64)
     psf_a = do.gaussian_psf((9, 9, 9), (2.0, 1.2, 1.2))
     psf_b = do.gaussian_psf((9, 9, 9), (1.2, 1.2, 2.0))
@@ -65,10 +74,10 @@ def test_reference_deconDualView_cli(tmp_path):
     assert rel_err(got, do.decon_dualview(a, b, psf_a, psf_b, 4)) < 1e-5
 
 
-def test_reference_reg3D_cli(tmp_path):
+def test_reg3D_cli(tmp_path, which):
     """reg3D with -regc 0 and an input matrix: the resample path of reg3d through the reference's main."""
     from microimagelib_amd import api
-    exe = _need("reg3D")
+    exe = _need("reg3D", which)
     tgt = do.blob_volume((16, 24, 32), n_blobs=8, seed=3)
     m = ro.dof9tomatrix(np.array([0, 0.7, -0.4, 0.3, 2.0, -1.0, 1.5, 1.01, 0.99, 1.0], dtype=np.float32), 9)
     api.writetifstack(str(tmp_path / "t.tif"), tgt, 32)
@@ -87,3 +96,24 @@ def test_reference_reg3D_cli(tmp_path):
     want = ro.affine_transform(tgt, m_file, tgt.shape)
     assert np.allclose(got, want, rtol=0, atol=1e-4 * float(np.max(np.abs(want))))
     assert os.path.exists(tmp_path / "out.tmx")
+
+
+def test_16bit_output_and_const_init(tmp_path, which):
+    """-bit 16 truncates like the reference writer ((uint16)f, src/apifunc.cpp:255); -cON uses the constant start."""
+    from microimagelib_amd import api
+    exe = _need("deconSingleView", which)
+    shape = (16, 32, 32)
+    psf = do.gaussian_psf((7, 7, 7), (1.5, 1.0, 1.0))
+    img = do.synthetic_view(shape, psf, seed=2, noise_seed=3, n_blobs=6)
+    api.writetifstack(str(tmp_path / "img.tif"), img, 16)  # 16-bit input: the tool reads what the writer truncated
+    api.writetifstack(str(tmp_path / "psf.tif"), psf, 32)
+    img16 = api.readtifstack(str(tmp_path / "img.tif"))
+    assert np.array_equal(img16, np.floor(img).astype(np.float32))
+    out = tmp_path / "decon.tif"
+    r = subprocess.run([exe, "-i", str(tmp_path / "img.tif"), "-fp", str(tmp_path / "psf.tif"), "-o", str(out),
+                        "-it", "3", "-cON", "-verbOFF"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert api.gettifinfo(str(out))[0] == 16  # same bit depth as the input image by default
+    want = do.decon_singleview(img16, psf, 3, const_init=True)
+    got = api.readtifstack(str(out))
+    assert np.max(np.abs(got - np.floor(want))) <= 1.0  # truncation of values that differ by rounding
