@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 
 namespace mil {
 namespace k {
@@ -319,6 +320,227 @@ __global__ __launch_bounds__(kSlabThreads) void corr_slab_kernel(const float *__
     }
 }
 
+// ---------------------------------------------------------------------------
+// z-marching cost kernel: LDS ring of source planes.
+//
+// A workgroup owns a 32 x 8 column of the target and marches through kMarchZ target planes.  The source
+// planes its current target plane needs (a window of 3-5 planes for near-axis-aligned matrices) live in a
+// power-of-two ring of LDS slots, slot = plane & (RING-1), each holding the x/y bounding box of the whole
+// column.  While step z is computed from LDS, the plane(s) step z+1 adds are already in flight from HBM
+// (one float4 per lane), and are dropped into their ring slots before the single barrier of the step.
+// Gathers thus cost LDS cycles (32 lanes/clk) instead of texture-address cycles (4 lanes/clk), staging is
+// overlapped, and LDS use is small enough for 6 workgroups per CU.  Bounding boxes are exact (monotone-corner
+// argument above); a column whose window does not fit the ring falls back to global pair gathers.
+// ---------------------------------------------------------------------------
+constexpr int kMX = 32, kMY = 16, kMarchZ = 64;  // target column per workgroup: 32 x 16 x 64
+constexpr int kMarchThreads = 256;                 // 32 x-lanes x 8 y-rows, two y sweeps per plane
+constexpr int kRingFloats = 7680;                  // 30 KB -> five workgroups per CU
+
+struct RingBox {
+    int x0, y0, bx, by, plane, n;  // plane = bx*by floats, n = ring slots
+};
+
+// slot of source plane p, given that plane `lo` sits in slot `slot_lo` and p - lo < n
+__device__ __forceinline__ int ring_slot(int p, int lo, int slot_lo, int n) {
+    int s = slot_lo + (p - lo);
+    return s >= n ? s - n : s;
+}
+
+__device__ __forceinline__ float fetch_linear_ring(const float *__restrict__ ring, const RingBox &rb, int wlo, int slot_lo,
+                                                   int sx, int sy, int sz, float tx, float ty, float tz) {
+    Tap X = make_tap(tx, sx), Y = make_tap(ty, sy), Z = make_tap(tz, sz);
+    const float *z0p = ring + ring_slot(Z.i0, wlo, slot_lo, rb.n) * rb.plane - rb.x0;
+    const float *z1p = ring + ring_slot(Z.i1, wlo, slot_lo, rb.n) * rb.plane - rb.x0;
+    const int r0 = (Y.i0 - rb.y0) * rb.bx, r1 = (Y.i1 - rb.y0) * rb.bx;
+    float c00 = X.w0 * z0p[r0 + X.i0] + X.w1 * z0p[r0 + X.i1];
+    float c01 = X.w0 * z0p[r1 + X.i0] + X.w1 * z0p[r1 + X.i1];
+    float c10 = X.w0 * z1p[r0 + X.i0] + X.w1 * z1p[r0 + X.i1];
+    float c11 = X.w0 * z1p[r1 + X.i0] + X.w1 * z1p[r1 + X.i1];
+    float c0 = Y.w0 * c00 + Y.w1 * c01;
+    float c1 = Y.w0 * c10 + Y.w1 * c11;
+    return Z.w0 * c0 + Z.w1 * c1;
+}
+
+// clamped tap range [lo, hi] of the z axis for the x/y tile at target plane fz
+__device__ __forceinline__ void z_window(const AffineArgs &a, const float *cx, const float *cy, float fz, int &lo, int &hi) {
+    float tmin = coord(a.m + 8, cx[0], cy[0], fz), tmax = tmin;
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        const float t = coord(a.m + 8, cx[c & 1], cy[c >> 1], fz);
+        tmin = fminf(tmin, t);
+        tmax = fmaxf(tmax, t);
+    }
+    const float fn = (float)a.sz;
+    const float lo_t = fminf(fmaxf(tmin, -2.0f), fn + 2.0f), hi_t = fminf(fmaxf(tmax, -2.0f), fn + 2.0f);
+    const int i0 = (int)floorf(lo_t - 0.5f), i1 = (int)floorf(hi_t - 0.5f) + 1;
+    lo = i0 < 0 ? 0 : (i0 > a.sz - 1 ? a.sz - 1 : i0);
+    hi = i1 < 0 ? 0 : (i1 > a.sz - 1 ? a.sz - 1 : i1);
+}
+
+__global__ __launch_bounds__(kMarchThreads) void corr_march_kernel(const float *__restrict__ tgt,
+                                                                 const float *__restrict__ src, AffineArgs a,
+                                                                 double *__restrict__ partials, int nblocks) {
+    __shared__ __attribute__((aligned(16))) float ring[kRingFloats];
+    __shared__ short win_lo[kMarchZ], win_hi[kMarchZ];
+    __shared__ double red[2 * (kMarchThreads / 64)];
+    const int X0 = blockIdx.x * kMX, Y0 = blockIdx.y * kMY, Z0 = blockIdx.z * kMarchZ;
+    const int X1 = min(X0 + kMX, a.tx) - 1, Y1 = min(Y0 + kMY, a.ty) - 1, Z1 = min(Z0 + kMarchZ, a.tz) - 1;
+    const int nzs = Z1 - Z0 + 1;
+    const float cx[2] = {(float)X0, (float)X1}, cy[2] = {(float)Y0, (float)Y1}, cz[2] = {(float)Z0, (float)Z1};
+    // ---- x / y bounding box of the whole column, ring geometry (wave-uniform)
+    int xl, xh, yl, yh;
+    axis_range(a.m + 0, cx, cy, cz, a.sx, xl, xh);
+    axis_range(a.m + 4, cx, cy, cz, a.sy, yl, yh);
+    RingBox rb;
+    rb.x0 = xl & ~3; rb.y0 = yl;
+    rb.bx = ((xh - rb.x0 + 1) + 3) & ~3; rb.by = yh - yl + 1;
+    rb.plane = rb.bx * rb.by;
+    rb.n = kRingFloats / rb.plane;
+    const int q4 = rb.bx >> 2, plane4 = q4 * rb.by;
+    const bool up = a.m[10] >= 0.0f;
+
+    // ---- per-plane windows, one lane each; the column is staged only if every step's window, together
+    // with the planes the next step adds, fits the ring and one float4 per lane covers a step's new planes
+    bool fits = rb.n >= 2 && a.sz <= 32767 && plane4 <= kMarchThreads;
+    if ((int)threadIdx.x < nzs) {
+        int lo, hi;
+        z_window(a, cx, cy, (float)(Z0 + (int)threadIdx.x), lo, hi);
+        win_lo[threadIdx.x] = (short)lo;
+        win_hi[threadIdx.x] = (short)hi;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nzs) {
+        const int i = threadIdx.x, j = min(i + 1, nzs - 1);
+        const int span = max(win_hi[i], win_hi[j]) - min(win_lo[i], win_lo[j]) + 1;
+        const int added = up ? (int)win_hi[j] - max((int)win_hi[i] + 1, (int)win_lo[j]) + 1
+                             : min((int)win_lo[i] - 1, (int)win_hi[j]) - (int)win_lo[j] + 1;
+        if (span > rb.n || added * plane4 > kMarchThreads) fits = false;
+    }
+    const bool staged = !__syncthreads_or(!fits);
+
+    // this lane's float4 of a staging sweep: plane offset, LDS offset, global offset (fixed per column)
+    const int s_pl = (int)threadIdx.x / plane4, s_r = (int)threadIdx.x - s_pl * plane4;
+    const int s_yy = s_r / q4, s_q = s_r - s_yy * q4;
+    const int s_lds = s_yy * rb.bx + 4 * s_q;
+    const float *s_src = src + (size_t)(rb.y0 + s_yy) * a.sx + rb.x0 + 4 * s_q;
+    const size_t src_plane = (size_t)a.sx * a.sy;
+
+    int wlo = win_lo[0], whi = win_hi[0], slot_lo = 0;  // plane wlo sits in slot slot_lo
+    if (staged) {  // prologue: the first window
+        const int per = kMarchThreads / plane4;  // whole planes per sweep (>= 1)
+        for (int p = wlo; p <= whi; p += per)
+            if (s_pl < min(per, whi - p + 1)) {
+                const int zp = p + s_pl;
+                *reinterpret_cast<float4 *>(ring + ring_slot(zp, wlo, 0, rb.n) * rb.plane + s_lds) =
+                    *reinterpret_cast<const float4 *>(s_src + (size_t)zp * src_plane);
+            }
+    }
+    __syncthreads();
+
+    // Everything step k reads from global memory -- this lane's piece of the planes first needed at step k
+    // ("A(k)") and its two target voxels -- is requested kDepth steps ahead into a register FIFO.  (vmcnt
+    // retires in issue order: a load consumed in the step that issued it would drain the whole queue.)
+    // A(k) is written to its ring slots at the end of step k-1, just before that step's barrier.
+    constexpr int kDepth = 8;
+    float4 fifo_v[kDepth];
+    int fifo_p[kDepth];
+    float fifo_t0[kDepth], fifo_t1[kDepth];
+    const int lx = threadIdx.x & (kMX - 1), ly = threadIdx.x >> 5;
+    const int x = X0 + lx, y0 = Y0 + ly, y1 = Y0 + ly + 8;
+    const bool act0 = x < a.tx && y0 < a.ty, act1 = x < a.tx && y1 < a.ty;
+    const size_t tstep = (size_t)a.tx * a.ty;
+    const float *tp0 = tgt + (size_t)(act0 ? x : 0) + (size_t)a.tx * ((size_t)(act0 ? y0 : 0) + (size_t)a.ty * Z0);
+    const float *tp1 = tgt + (size_t)(act1 ? x : 0) + (size_t)a.tx * ((size_t)(act1 ? y1 : 0) + (size_t)a.ty * Z0);
+    auto request = [&](int k, float4 &v, int &zp_out, float &t0, float &t1) {
+        zp_out = -1;
+        if (k < nzs) {
+            if (act0) t0 = tp0[(size_t)k * tstep];
+            if (act1) t1 = tp1[(size_t)k * tstep];
+            if (staged && k > 0) {
+                const int plo = win_lo[k - 1], phi = win_hi[k - 1], nlo = win_lo[k], nhi = win_hi[k];
+                const int add_lo = up ? max(phi + 1, nlo) : nlo;
+                const int count = (up ? nhi : min(plo - 1, nhi)) - add_lo + 1;
+                if (s_pl < count) {
+                    zp_out = add_lo + s_pl;
+                    v = *reinterpret_cast<const float4 *>(s_src + (size_t)zp_out * src_plane);
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) {
+        fifo_v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        fifo_t0[j] = fifo_t1[j] = 0.f;
+        request(j, fifo_v[j], fifo_p[j], fifo_t0[j], fifo_t1[j]);  // steps 0 .. kDepth-1
+    }
+
+    const float ix = (float)x;
+    double ss = 0.0, st = 0.0;
+    for (int base = 0; base < nzs; base += kDepth) {
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) {
+            const int zi = base + j;
+            if (zi >= nzs) break;
+            const float iz = (float)(Z0 + zi);
+            const float tv0 = fifo_t0[j], tv1 = fifo_t1[j];  // requested kDepth steps ago
+            request(zi + kDepth, fifo_v[j], fifo_p[j], fifo_t0[j], fifo_t1[j]);  // slot j's planes are in the ring already
+#pragma unroll
+            for (int sweep = 0; sweep < 2; ++sweep) {
+                if (sweep == 0 ? act0 : act1) {
+                    const float iy = (float)(sweep == 0 ? y0 : y1);
+                    const float tx = coord(a.m + 0, ix, iy, iz);
+                    const float ty = coord(a.m + 4, ix, iy, iz);
+                    const float tz = coord(a.m + 8, ix, iy, iz);
+                    float sv = 0.0f;
+                    if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
+                        sv = staged ? fetch_linear_ring(ring, rb, wlo, slot_lo, a.sx, a.sy, a.sz, tx, ty, tz)
+                                    : fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
+                    const float tv = sweep == 0 ? tv0 : tv1;
+                    ss += (double)sv * (double)sv;
+                    st += (double)sv * (double)tv;
+                }
+            }
+            if (staged && zi + 1 < nzs) {
+                // commit A(zi+1); offsets from wlo stay within (-n, n)
+                const int jn = (j + 1) % kDepth;  // static after unrolling
+                if (fifo_p[jn] >= 0) {
+                    int sl = slot_lo + (fifo_p[jn] - wlo);
+                    sl = sl >= rb.n ? sl - rb.n : (sl < 0 ? sl + rb.n : sl);
+                    *reinterpret_cast<float4 *>(ring + sl * rb.plane + s_lds) = fifo_v[jn];
+                }
+                __syncthreads();
+                const int nlo = win_lo[zi + 1];
+                int sl = slot_lo + (nlo - wlo);
+                slot_lo = sl >= rb.n ? sl - rb.n : (sl < 0 ? sl + rb.n : sl);
+                wlo = nlo;
+                whi = win_hi[zi + 1];
+            }
+        }
+    }
+    (void)whi;
+    (void)tstep;
+    ss = wave_sum(ss);
+    st = wave_sum(st);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = kMarchThreads / 64;
+    if (lane == 0) {
+        red[wave] = ss;
+        red[NW + wave] = st;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            a0 += red[w];
+            a1 += red[NW + w];
+        }
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        partials[b] = a0;
+        partials[nblocks + b] = a1;
+    }
+}
+
 constexpr int kFinalThreads = 1024;
 __global__ __launch_bounds__(kFinalThreads) void corr_final_kernel(const double *__restrict__ partials, int count,
                                                                  double *__restrict__ out) {
@@ -378,17 +600,30 @@ CorrWorkspace::~CorrWorkspace() {
 void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
                      CorrWorkspace &ws, hipStream_t s) {
     AffineArgs a = make_args(t_dims, s_dims, m);
-    // slab staging uses aligned float4 rows of the source; anything else takes the direct-gather kernel
-    static const bool use_slab = getenv("MIL_CORR_SLAB") && getenv("MIL_CORR_SLAB")[0] == '1';
-    const bool slab_ok = use_slab && (a.sx % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    dim3 grid = slab_ok ? dim3((a.tx + kLX - 1) / kLX, (a.ty + kLY - 1) / kLY, (a.tz + kLZ - 1) / kLZ)
-                        : dim3((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
+    // LDS staging uses aligned float4 rows of the source; anything else takes the direct-gather kernel.
+    // MIL_CORR_MODE = march (default) | direct | slab selects the kernel (A/B experiments).
+    static const int mode = [] {
+        const char *e = getenv("MIL_CORR_MODE");
+        if (e && !strcmp(e, "direct")) return 0;
+        if (e && !strcmp(e, "slab")) return 1;
+        return 2;
+    }();
+    const bool lds_ok = (a.sx % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const int kind = lds_ok ? mode : 0;
+    dim3 grid;
+    if (kind == 2) grid = dim3((a.tx + kMX - 1) / kMX, (a.ty + kMY - 1) / kMY, (a.tz + kMarchZ - 1) / kMarchZ);
+    else if (kind == 1) grid = dim3((a.tx + kLX - 1) / kLX, (a.ty + kLY - 1) / kLY, (a.tz + kLZ - 1) / kLZ);
+    else grid = dim3((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
     if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
-    if (slab_ok)
-        hipLaunchKernelGGL(corr_slab_kernel, grid, dim3(kSlabThreads), 0, s, target, src, a, ws.partials.get(), (int)nblocks);
+    if (kind == 2)
+        hipLaunchKernelGGL(corr_march_kernel, grid, dim3(kMarchThreads), 0, s, target, src, a, ws.partials.get(),
+                           (int)nblocks);
+    else if (kind == 1)
+        hipLaunchKernelGGL(corr_slab_kernel, grid, dim3(kSlabThreads), 0, s, target, src, a, ws.partials.get(),
+                           (int)nblocks);
     else
         hipLaunchKernelGGL(corr_kernel, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
                            (int)nblocks);

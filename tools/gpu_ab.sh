@@ -1,6 +1,4 @@
 cd /root/repo
-for i in 1 2; do
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('events   ', d['value'], d['ms_per_step'])"
-MIL_BENCH_NO_EVENTS=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('no events', d['value'], d['ms_per_step'])"
-done
-python bench.py --steps 100 --warmup 3 --no-cpu-baseline --no-extra | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('events K=100', d['value'], d['ms_per_step'])"
+timeout 900 python -m pytest tests/test_gpu_reg.py tests/test_gpu_kernels.py tests/test_gpu_cli.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head
+echo "--- march"; timeout 300 python tools/bench_corr.py 2>/dev/null
+echo "--- direct"; MIL_CORR_MODE=direct timeout 300 python tools/bench_corr.py 2>/dev/null
