@@ -56,6 +56,15 @@ def synth_volume(torch, shape, psf, seed):
     return noisy.float().contiguous()
 
 
+def gaussian_psf(shape, sigma_zyx):
+    """Synthetic input only: unnormalised anisotropic Gaussian PSF centred at shape // 2 (SURVEY.md section 8d)."""
+    g = []
+    for s, sg in zip(shape, sigma_zyx):
+        c = np.arange(s, dtype=np.float64) - s // 2
+        g.append(np.exp(-0.5 * (c / sg) ** 2))
+    return (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
+
+
 def cpu_baseline(img_host, psf_host, iters):
     """Oracle (NumPy restatement of decon_singleview_OTF1) on the host: `iters` RL iterations."""
     from oracle import decon_oracle as do
@@ -103,7 +112,6 @@ def main():
     lib = _lib.load()
     assert lib.mil_set_device(local_rank) == 0
 
-    from oracle.decon_oracle import gaussian_psf  # PSF definition shared with the tests (tiny, host side)
     psf_a_host = gaussian_psf(PSF_SHAPE, (6.0, 2.5, 2.5))  # sigma (z, y, x)
     psf_b_host = gaussian_psf(PSF_SHAPE, (2.5, 2.5, 6.0))
     psf_a = torch.from_numpy(psf_a_host).cuda()

@@ -46,7 +46,8 @@ int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, 
 /* ---- deconvolution engine -------------------------------------------------- */
 typedef struct mil_decon mil_decon;
 /* Transform backends of the engine.  FUSED: hand-written LDS-tiled transforms with the OTF
- * product, RL ratio and estimate update fused in (power-of-two boxes, 16..1024, x <= 2048);
+ * product, RL ratio and estimate update fused in (every snapTransformSize box up to 1024 per axis:
+ * powers of two from 16 and multiples of 64 from 192; x also 2048);
  * ROCFFT: rocFFT plans + separate element-wise kernels (any box).  AUTO picks FUSED when the
  * box allows it.  OTF / spectrum buffers are opaque: `mil_decon_spectrum_count` complex64
  * elements, layout private to the backend (mil_decon_otf_to_natural converts). */
@@ -66,8 +67,8 @@ size_t mil_decon_spectrum_count(const mil_decon *e);
 int mil_decon_convolve(mil_decon *e, float *d_out, const float *d_in, const void *d_otf);
 /* engine OTF -> natural [nz][ny][nx/2+1] complex64 (the cufftExecR2C output order, :3298-3299) */
 int mil_decon_otf_to_natural(mil_decon *e, void *d_natural, const void *d_otf);
-/* host only: freq_of_pos[p] = frequency index held at position p after the in-place
- * mixed-radix (8,..,8,{2,4}) forward transform of length n (power of two) */
+/* host only: freq_of_pos[p] = frequency index held at position p after the in-place mixed-radix
+ * (8,..,8,{4,2},{3,5,7,11,13}) forward transform of length n (prime factors <= 13) */
 int mil_fft_digit_reversal(int n, unsigned short *freq_of_pos);
 /* genOTFgpu :3269 (flip != 0 applies flipgpu first: matched back projector) */
 int mil_decon_gen_otf(mil_decon *e, void *d_otf, const float *d_psf, int px, int py, int pz, int flip);

@@ -118,7 +118,11 @@ int mil_decon_otf_to_natural(mil_decon *e, void *d_natural, const void *d_otf) {
     });
 }
 int mil_fft_digit_reversal(int n, unsigned short *freq_of_pos) {
-    if (n < 1 || n > 65536 || (n & (n - 1))) return -1;
+    if (n < 1 || n > 65535) return -1;
+    int rest = n;
+    for (int r : {2, 3, 5, 7, 11, 13})
+        while (rest % r == 0) rest /= r;
+    if (rest != 1) return -1;  // prime factor the transforms have no radix for
     fx::digit_reversal_freq(n, freq_of_pos);
     return 0;
 }

@@ -90,11 +90,74 @@ __device__ __forceinline__ void dft8(float2 *v) {
     v[7] = c_sub(e3, o3);
 }
 
+// cos / sin(2*pi*k/R) for the odd radices
+template <int R>
+struct OddTable;
+template <>
+struct OddTable<3> {
+    static constexpr float c[3] = {1.0f, -0.49999999999999978f, -0.50000000000000044f};
+    static constexpr float s[3] = {0.0f, 0.86602540378443871f, -0.86602540378443837f};
+};
+template <>
+struct OddTable<5> {
+    static constexpr float c[5] = {1.0f, 0.30901699437494745f, -0.80901699437494734f, -0.80901699437494756f, 0.30901699437494723f};
+    static constexpr float s[5] = {0.0f, 0.95105651629515353f, 0.58778525229247325f, -0.58778525229247303f, -0.95105651629515364f};
+};
+template <>
+struct OddTable<7> {
+    static constexpr float c[7] = {1.0f, 0.62348980185873359f, -0.22252093395631434f, -0.90096886790241903f, -0.90096886790241915f, -0.22252093395631459f, 0.62348980185873337f};
+    static constexpr float s[7] = {0.0f, 0.7818314824680298f, 0.97492791218182362f, 0.43388373911755823f, -0.43388373911755801f, -0.97492791218182362f, -0.78183148246802991f};
+};
+template <>
+struct OddTable<11> {
+    static constexpr float c[11] = {1.0f, 0.84125353283118121f, 0.41541501300188644f, -0.142314838273285f, -0.65486073394528499f, -0.95949297361449737f, -0.95949297361449748f, -0.65486073394528521f, -0.14231483827328523f, 0.41541501300188605f, 0.84125353283118121f};
+    static constexpr float s[11] = {0.0f, 0.54064081745559756f, 0.90963199535451833f, 0.9898214418809328f, 0.75574957435425827f, 0.28173255684142967f, -0.28173255684142939f, -0.75574957435425816f, -0.98982144188093268f, -0.90963199535451855f, -0.54064081745559744f};
+};
+template <>
+struct OddTable<13> {
+    static constexpr float c[13] = {1.0f, 0.88545602565320991f, 0.56806474673115592f, 0.12053668025532301f, -0.35460488704253545f, -0.74851074817110119f, -0.97094181742605201f, -0.97094181742605212f, -0.7485107481711013f, -0.3546048870425359f, 0.1205366802553232f, 0.56806474673115481f, 0.88545602565321002f};
+    static constexpr float s[13] = {0.0f, 0.46472317204376851f, 0.82298386589365635f, 0.99270887409805397f, 0.93501624268541483f, 0.66312265824079519f, 0.23931566428755768f, -0.23931566428755743f, -0.66312265824079497f, -0.93501624268541472f, -0.99270887409805397f, -0.82298386589365702f, -0.4647231720437684f};
+};
+
+// R-point DFT for odd prime R by definition, folded over conjugate pairs:
+//   out[k], out[R-k] = (v0 + sum_j (v_j + v_(R-j)) cos(jk)) +/- SIGN*i * sum_j (v_j - v_(R-j)) sin(jk)
+template <int R, int SIGN>
+__device__ __forceinline__ void dft_odd(float2 *v) {
+    constexpr int H = (R - 1) / 2;
+    float2 a[H], b[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        a[j] = c_add(v[j + 1], v[R - 1 - j]);
+        b[j] = c_sub(v[j + 1], v[R - 1 - j]);
+    }
+    const float2 v0 = v[0];
+    float2 sum = v0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) sum = c_add(sum, a[j]);
+    v[0] = sum;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        float2 p = v0, q = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int e = ((j + 1) * k) % R;
+            p.x += a[j].x * OddTable<R>::c[e];
+            p.y += a[j].y * OddTable<R>::c[e];
+            q.x += b[j].x * OddTable<R>::s[e];
+            q.y += b[j].y * OddTable<R>::s[e];
+        }
+        const float2 iq = (SIGN > 0) ? make_float2(-q.y, q.x) : make_float2(q.y, -q.x);  // SIGN * i * q
+        v[k] = c_add(p, iq);
+        v[R - k] = c_sub(p, iq);
+    }
+}
+
 template <int R, int SIGN>
 __device__ __forceinline__ void dft_small(float2 *v) {
-    if (R == 8) dft8<SIGN>(v);
-    else if (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
-    else dft2<SIGN>(v);
+    if constexpr (R == 8) dft8<SIGN>(v);
+    else if constexpr (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
+    else if constexpr (R == 2) dft2<SIGN>(v);
+    else dft_odd<R, SIGN>(v);
 }
 
 // One radix-R pass over sub-transforms of length L of an N x 16 tile.
@@ -131,9 +194,15 @@ __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float
     }
 }
 
+// Radix schedule of a length-L sub-transform: 8s first, then 4 / 2, then the odd primes of the
+// 64*k sizes snapTransformSize produces (192 = 8*8*3, 320 = 8*8*5, ... 960 = 8*8*3*5).
+constexpr int pick_radix(int L) {
+    return (L % 8 == 0) ? 8 : (L % 4 == 0) ? 4 : (L % 2 == 0) ? 2 : (L % 3 == 0) ? 3 : (L % 5 == 0) ? 5
+         : (L % 7 == 0) ? 7 : (L % 11 == 0) ? 11 : (L % 13 == 0) ? 13 : L;
+}
 template <int L>
 struct Radix {
-    static constexpr int value = (L % 8 == 0) ? 8 : L;  // remainder 2 or 4 goes last
+    static constexpr int value = pick_radix(L);
 };
 
 // Barrier contract: the tile must be complete (barrier done) on entry; on return every
@@ -437,13 +506,19 @@ __global__ void otf_to_natural_kernel(float2 *__restrict__ nat, const float2 *__
 
 bool pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// lengths the column kernels are instantiated for: powers of two and the 64*k sizes of snapTransformSize
+bool col_length_ok(long long n) {
+    if (n < 16 || n > 1024) return false;
+    return pow2(n) || (n >= 192 && n % 64 == 0);
+}
+
 void freq_rec(int n, int pos_base, int freq_mul, int freq_add, unsigned short *out) {
     // position p of a length-n sub-transform holds frequency r*freq(p % m) + p / m
     if (n == 1) {
         out[pos_base] = (unsigned short)freq_add;
         return;
     }
-    const int r = (n % 8 == 0) ? 8 : n;
+    const int r = pick_radix(n);
     const int m = n / r;
     for (int k2 = 0; k2 < r; ++k2) freq_rec(m, pos_base + k2 * m, freq_mul * r, freq_add + k2 * freq_mul, out);
 }
@@ -478,6 +553,17 @@ void dispatch_col(int n, const ColArgs &a, long long blocks, hipStream_t s) {
         case 256: launch_col<256>(a, blocks, s); break;
         case 512: launch_col<512>(a, blocks, s); break;
         case 1024: launch_col<1024>(a, blocks, s); break;
+        case 192: launch_col<192>(a, blocks, s); break;
+        case 320: launch_col<320>(a, blocks, s); break;
+        case 384: launch_col<384>(a, blocks, s); break;
+        case 448: launch_col<448>(a, blocks, s); break;
+        case 576: launch_col<576>(a, blocks, s); break;
+        case 640: launch_col<640>(a, blocks, s); break;
+        case 704: launch_col<704>(a, blocks, s); break;
+        case 768: launch_col<768>(a, blocks, s); break;
+        case 832: launch_col<832>(a, blocks, s); break;
+        case 896: launch_col<896>(a, blocks, s); break;
+        case 960: launch_col<960>(a, blocks, s); break;
         default: throw Error(-1, "fused FFT: unsupported column length");
     }
     MIL_HIP(hipGetLastError());
@@ -496,12 +582,11 @@ void launch_x(int mode, const XArgs &a, long long rows, hipStream_t s) {
     }
 }
 
-void dispatch_x(int nh, int rb, int mode, const XArgs &a, long long rows, hipStream_t s) {
+void dispatch_x(int nh, int mode, const XArgs &a, long long rows, hipStream_t s) {
     if (rows <= 0 || rows % 16 || rows / 8 > 0x7fffffffLL) throw Error(-1, "fused FFT: row count out of range");
-#define MIL_X_CASE(NHV)                                              \
-    case NHV:                                                        \
-        if (rb == 8) launch_x<NHV, 8>(mode, a, rows, s);             \
-        else launch_x<NHV, 16>(mode, a, rows, s);                    \
+#define MIL_X_CASE(NHV)                      \
+    case NHV:                                \
+        launch_x<NHV, 8>(mode, a, rows, s);  \
         break;
     switch (nh) {
         MIL_X_CASE(8)
@@ -512,6 +597,17 @@ void dispatch_x(int nh, int rb, int mode, const XArgs &a, long long rows, hipStr
         MIL_X_CASE(256)
         MIL_X_CASE(512)
         MIL_X_CASE(1024)
+        MIL_X_CASE(96)
+        MIL_X_CASE(160)
+        MIL_X_CASE(192)
+        MIL_X_CASE(224)
+        MIL_X_CASE(288)
+        MIL_X_CASE(320)
+        MIL_X_CASE(352)
+        MIL_X_CASE(384)
+        MIL_X_CASE(416)
+        MIL_X_CASE(448)
+        MIL_X_CASE(480)
         default: throw Error(-1, "fused FFT: unsupported row length");
     }
 #undef MIL_X_CASE
@@ -534,15 +630,14 @@ void digit_reversal_pos(int n, unsigned short *pos_of_elem) {
 }
 
 bool ConvPlan::supported(Dims b) {
-    return pow2(b.nx) && pow2(b.ny) && pow2(b.nz) && b.nx >= 16 && b.nx <= 2048 && b.ny >= 16 && b.ny <= 1024 &&
-           b.nz >= 16 && b.nz <= 1024;
+    const bool x_ok = (pow2(b.nx) && b.nx >= 16 && b.nx <= 2048) || (b.nx >= 192 && b.nx <= 1024 && b.nx % 64 == 0);
+    return x_ok && col_length_ok(b.ny) && col_length_ok(b.nz);
 }
 
 ConvPlan::ConvPlan(Dims box) : box_(box) {
-    if (!supported(box)) throw Error(-1, "ConvPlan: box is not a supported power-of-two size");
+    if (!supported(box)) throw Error(-1, "ConvPlan: unsupported box (need powers of two or multiples of 64, 16..1024, x up to 2048)");
     const int nx = (int)box.nx, ny = (int)box.ny, nz = (int)box.nz, nh = nx / 2;
     xs_ = ((nh + 1 + kW - 1) / kW) * kW;
-    x_rows_ = env_int("MIL_FX_XROWS", 8) == 16 ? 16 : 8;
     ablate_ = env_int("MIL_FX_ABLATE", 0);
     upload(tw_x_, twiddles(nx));
     upload(tw_y_, twiddles(ny));
@@ -564,7 +659,7 @@ void ConvPlan::x_pass(XMode mode, float2 *S, const float *rin, float *rout, cons
     a.S = S; a.rin = rin; a.rout = rout; a.M = M;
     a.tw = tw_x_.get(); a.pos = pos_x_.get(); a.eps = eps; a.reverse = reverse ? 1 : 0;
     a.ablate = ablate_;
-    dispatch_x((int)box_.nx / 2, x_rows_, (int)mode, a, box_.ny * box_.nz, s);
+    dispatch_x((int)box_.nx / 2, (int)mode, a, box_.ny * box_.nz, s);
 }
 
 void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s, bool reverse) const {

@@ -13,8 +13,9 @@
 // One view update = 8 launches moving 18 C' + 3 R bytes instead of ~26 C + 12 R (C' = padded
 // half spectrum, R = real volume).  Spectra live in a PRIVATE layout (y and z in the digit-reversed
 // order the in-place transforms leave them in, x padded to a multiple of 16 columns, OTFs tiled per
-// z-conv workgroup); nothing outside this module depends on it.  Power-of-two boxes only
-// (16..1024 per axis, x up to 2048); other boxes use the rocFFT path in decon.cpp.
+// z-conv workgroup); nothing outside this module depends on it.  Boxes: every size snapTransformSize
+// produces up to 1024 per axis (powers of two from 16, and the multiples of 64 from 192: radices
+// 8/4/2 plus 3, 5, 7, 11, 13), x also 2048; anything else uses the rocFFT path in decon.cpp.
 #pragma once
 
 #include "mil_common.h"
@@ -57,7 +58,6 @@ public:
 private:
     Dims box_;
     int xs_ = 0;
-    int x_rows_ = 8;   // rows per x-pass workgroup (8 or 16; MIL_FX_XROWS)
     int ablate_ = 0;   // MIL_FX_ABLATE: timing experiments only, results are wrong when non-zero
     DeviceBuffer<float2> tw_x_, tw_y_, tw_z_;   // exp(-2*pi*i*k/n), k in [0, n)
     DeviceBuffer<unsigned short> pos_x_;        // position of element n after digit reversal, n in [0, nx/2)

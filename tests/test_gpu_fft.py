@@ -9,7 +9,10 @@ from oracle import decon_oracle as do
 pytestmark = pytest.mark.gpu
 f32 = np.float32
 
-SHAPES = [(16, 16, 16), (32, 16, 64), (16, 64, 32), (64, 32, 128), (128, 128, 128), (32, 256, 512), (256, 64, 16)]
+SHAPES = [(16, 16, 16), (32, 16, 64), (16, 64, 32), (64, 32, 128), (128, 128, 128), (32, 256, 512), (256, 64, 16),
+          # the 64*k boxes of snapTransformSize: radices 3, 5, 7, 11, 13 on every axis
+          (16, 192, 320), (192, 16, 384), (320, 64, 192), (64, 448, 448), (16, 704, 576), (576, 16, 704),
+          (16, 832, 640), (896, 16, 832), (16, 960, 896), (640, 16, 960), (16, 768, 768), (768, 32, 64)]
 
 
 @pytest.fixture(scope="module")
@@ -79,7 +82,28 @@ def test_backends_agree_on_rl(dev):
         assert float(np.max(np.abs(o - want) / np.maximum(np.abs(want), floor))) < 1e-5
 
 
-def test_non_power_of_two_box_uses_rocfft(dev):
+def test_snap_sized_box_runs_rl_on_the_fused_backend(dev):
+    """A 50x180x300 stack snaps to 64x192x320 (radices 3 and 5): fused backend, parity with the oracle."""
+    import torch
+    shape = (64, 192, 320)
+    psf = do.gaussian_psf((15, 15, 15), (3.0, 1.5, 1.5))
+    img = do.synthetic_view(shape, psf, seed=5, noise_seed=6, n_blobs=20)
+    eng = dev.DeconEngine(shape)
+    assert eng.backend == dev.DeconEngine.FUSED
+    A = T(img)
+    E = torch.empty_like(A)
+    otf, bp = eng.gen_otf(T(psf)), eng.gen_otf(T(psf), flip=True)
+    eng.init_single(A, E)
+    eng.run_single(E, A, otf, bp, 8)
+    eng.sync()
+    got = E.cpu().numpy()
+    eng.close()
+    want = do.decon_singleview(img, psf, 8)
+    floor = float(np.mean(np.abs(want)))
+    assert float(np.max(np.abs(got - want) / np.maximum(np.abs(want), floor))) < 1e-5
+
+
+def test_unsupported_box_uses_rocfft(dev):
     eng = dev.DeconEngine((32, 48, 192))
     assert eng.backend == dev.DeconEngine.ROCFFT
     eng.close()

@@ -84,7 +84,7 @@ def test_checkmatrix_table(lib, tables):
 
 def test_fft_digit_reversal_tables():
     """Host tables of the fused transform backend: freq_of_pos for the in-place mixed-radix
-    (8,..,8,{2,4}) decimation-in-frequency plan, checked against a NumPy model of that plan."""
+    (8,..,8,{4,2},{3,5,7,11,13}) decimation-in-frequency plan, checked against a NumPy model of that plan."""
     import ctypes as C
     from microimagelib_amd import _lib
     lib = _lib.load()
@@ -92,16 +92,16 @@ def test_fft_digit_reversal_tables():
     def model(n):
         if n == 1:
             return np.zeros(1, dtype=np.int64)
-        r = 8 if n % 8 == 0 else n
+        r = next(r for r in (8, 4, 2, 3, 5, 7, 11, 13) if n % r == 0)
         m = n // r
         sub = model(m)
         p = np.arange(n)
         return r * sub[p % m] + p // m
 
-    for n in (8, 16, 32, 64, 128, 256, 512, 1024):
+    for n in (8, 16, 32, 64, 128, 256, 512, 1024, 96, 160, 192, 320, 352, 416, 448, 576, 704, 832, 896, 960):
         buf = (C.c_ushort * n)()
         assert lib.mil_fft_digit_reversal(n, buf) == 0
         got = np.frombuffer(buf, dtype=np.uint16).astype(np.int64)
         assert np.array_equal(got, model(n))
         assert np.array_equal(np.sort(got), np.arange(n))
-    assert lib.mil_fft_digit_reversal(24, (C.c_ushort * 24)()) == -1
+    assert lib.mil_fft_digit_reversal(0, (C.c_ushort * 4)()) == -1

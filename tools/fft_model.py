@@ -7,13 +7,17 @@ and the 3-pass convolution with a privately ordered OTF.
 import numpy as np
 
 
+def pick_radix(n):
+    for r in (8, 4, 2, 3, 5, 7, 11, 13):
+        if n % r == 0:
+            return r
+    raise ValueError(n)
+
+
 def plan(n):
     r = []
-    while n % 8 == 0:
-        r.append(8); n //= 8
-    if n > 1:
-        assert n in (2, 4), n
-        r.append(n)
+    while n > 1:
+        r.append(pick_radix(n)); n //= r[-1]
     return r
 
 
@@ -117,7 +121,7 @@ def irfft3_private(s):
 
 if __name__ == "__main__":
     rng = np.random.default_rng(0)
-    for n in (8, 16, 32, 64, 128, 256, 512, 1024):
+    for n in (8, 16, 32, 64, 128, 256, 512, 1024, 96, 160, 192, 224, 320, 352, 416, 448, 576, 960):
         x = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
         fm = freq_map(n, plan(n))
         want = np.fft.fft(x, axis=0)
@@ -127,7 +131,7 @@ if __name__ == "__main__":
         v = np.zeros_like(x); v[pos] = x
         assert np.allclose(fft_dit(v, -1), want), n
         assert np.allclose(fft_dit(fft_dif(x, -1), +1), n * x), n
-    for shape in ((16, 16, 16), (16, 32, 64), (32, 16, 128)):
+    for shape in ((16, 16, 16), (16, 32, 64), (32, 16, 128), (16, 192, 320)):
         vol = rng.standard_normal(shape)
         nz, ny, nx = shape
         S = rfft3_private(vol)
