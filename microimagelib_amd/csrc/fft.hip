@@ -163,16 +163,16 @@ __device__ __forceinline__ void dft_small(float2 *v) {
 // One radix-R pass over sub-transforms of length L of an N x 16 tile.
 //   DIF: y_k = w_L^(i*k) * DFT_R(x)[k]      DIT: y = DFT_R( w_L^(i*k) * x_k )
 // Lane mapping: column fastest (16 lanes), then butterfly index.
-template <int N, int R, int L, bool DIT, int SIGN, int W = kW>
+template <int N, int R, int L, bool DIT, int SIGN, int W = kW, int NT = kNT>
 __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float2 *__restrict__ tw) {
     constexpr int WP = W + 1;
     constexpr int M = L / R;            // butterflies per sub-transform
     constexpr int NB = (N / R) * W;     // butterflies in the tile
     constexpr int TWS = N / L;          // table step: w_L = w_N^(N/L)
 #pragma unroll
-    for (int it = 0; it < (NB + kNT - 1) / kNT; ++it) {
-        const int idx = it * kNT + (int)threadIdx.x;
-        if ((NB % kNT) != 0 && idx >= NB) break;
+    for (int it = 0; it < (NB + NT - 1) / NT; ++it) {
+        const int idx = it * NT + (int)threadIdx.x;
+        if ((NB % NT) != 0 && idx >= NB) break;
         const int c = idx % W;
         const int b = idx / W;
         const int blk = b / M, i = b % M;
@@ -207,21 +207,21 @@ struct Radix {
 
 // Barrier contract: the tile must be complete (barrier done) on entry; on return every
 // stage has been followed by a barrier.
-template <int N, int L, int SIGN, int W = kW>
+template <int N, int L, int SIGN, int W = kW, int NT = kNT>
 __device__ __forceinline__ void fft_dif(float2 *tile, const float2 *tw) {
     if constexpr (L > 1) {
         constexpr int R = Radix<L>::value;
-        fft_stage<N, R, L, false, SIGN, W>(tile, tw);
+        fft_stage<N, R, L, false, SIGN, W, NT>(tile, tw);
         __syncthreads();
-        fft_dif<N, L / R, SIGN, W>(tile, tw);
+        fft_dif<N, L / R, SIGN, W, NT>(tile, tw);
     }
 }
-template <int N, int L, int SIGN, int W = kW>
+template <int N, int L, int SIGN, int W = kW, int NT = kNT>
 __device__ __forceinline__ void fft_dit(float2 *tile, const float2 *tw) {
     if constexpr (L > 1) {
         constexpr int R = Radix<L>::value;
-        fft_dit<N, L / R, SIGN, W>(tile, tw);
-        fft_stage<N, R, L, true, SIGN, W>(tile, tw);
+        fft_dit<N, L / R, SIGN, W, NT>(tile, tw);
+        fft_stage<N, R, L, true, SIGN, W, NT>(tile, tw);
         __syncthreads();
     }
 }
@@ -243,20 +243,20 @@ struct ColArgs {
     int reverse;           // walk the tiles last-to-first (ping-pong with the previous kernel: Infinity Cache reuse)
 };
 
-template <int N>
+template <int N, int NT>
 __device__ __forceinline__ void tile_load(float2 *__restrict__ tile, const float2 *__restrict__ base, long long stride) {
     constexpr int TOTAL = N * 8;  // float4 pieces
 #pragma unroll 1
-    for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
+    for (int it0 = 0; it0 < TOTAL; it0 += NT * kBatch) {
         float4 v[kBatch];
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            const int idx = it0 + j * NT + (int)threadIdx.x;
             if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(base + (long long)(idx >> 3) * stride + 2 * (idx & 7));
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            const int idx = it0 + j * NT + (int)threadIdx.x;
             if (idx < TOTAL) {
                 float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
                 q[0] = make_float2(v[j].x, v[j].y);
@@ -266,11 +266,11 @@ __device__ __forceinline__ void tile_load(float2 *__restrict__ tile, const float
     }
 }
 
-template <int N>
+template <int N, int NT>
 __device__ __forceinline__ void tile_store(const float2 *__restrict__ tile, float2 *__restrict__ base, long long stride) {
     constexpr int TOTAL = N * 8;
 #pragma unroll 4
-    for (int idx = (int)threadIdx.x; idx < TOTAL; idx += kNT) {
+    for (int idx = (int)threadIdx.x; idx < TOTAL; idx += NT) {
         const float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
         const float2 a = q[0], b = q[1];
         *reinterpret_cast<float4 *>(base + (long long)(idx >> 3) * stride + 2 * (idx & 7)) = make_float4(a.x, a.y, b.x, b.y);
@@ -278,20 +278,20 @@ __device__ __forceinline__ void tile_store(const float2 *__restrict__ tile, floa
 }
 
 // tile[p][c] *= otf[p][c], otf tile contiguous [N][16]
-template <int N>
+template <int N, int NT>
 __device__ __forceinline__ void tile_mul(float2 *__restrict__ tile, const float2 *__restrict__ otf) {
     constexpr int TOTAL = N * 8;
 #pragma unroll 1
-    for (int it0 = 0; it0 < TOTAL; it0 += kNT * kBatch) {
+    for (int it0 = 0; it0 < TOTAL; it0 += NT * kBatch) {
         float4 v[kBatch];
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            const int idx = it0 + j * NT + (int)threadIdx.x;
             if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(otf + 2 * idx);
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kNT + (int)threadIdx.x;
+            const int idx = it0 + j * NT + (int)threadIdx.x;
             if (idx < TOTAL) {
                 float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
                 q[0] = c_mul(q[0], make_float2(v[j].x, v[j].y));
@@ -301,36 +301,36 @@ __device__ __forceinline__ void tile_mul(float2 *__restrict__ tile, const float2
     }
 }
 
-template <int N>
-__global__ __launch_bounds__(kNT) void col_kernel(ColArgs a) {
+template <int N, int NT>
+__global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
     __shared__ float2 tile[N * kWP];
     __shared__ float2 tw[N];
     const unsigned bid = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int g = bid % a.groups;
     const long long outer = bid / a.groups;
     float2 *base = a.S + outer * a.outer_stride + (long long)g * kW;
-    for (int k = threadIdx.x; k < N; k += kNT) tw[k] = a.tw[k];
-    tile_load<N>(tile, base, a.row_stride);
+    for (int k = threadIdx.x; k < N; k += NT) tw[k] = a.tw[k];
+    tile_load<N, NT>(tile, base, a.row_stride);
     __syncthreads();
     if (a.mode == kColInverse) {
-        fft_dit<N, N, +1>(tile, tw);
-        tile_store<N>(tile, base, a.row_stride);
+        fft_dit<N, N, +1, kW, NT>(tile, tw);
+        tile_store<N, NT>(tile, base, a.row_stride);
         return;
     }
-    fft_dif<N, N, -1>(tile, tw);
+    fft_dif<N, N, -1, kW, NT>(tile, tw);
     if (a.mode == kColForward) {
-        tile_store<N>(tile, base, a.row_stride);
+        tile_store<N, NT>(tile, base, a.row_stride);
         return;
     }
     const long long otf_tile = (long long)bid * N * kW;  // [outer][g][N][16]
     if (a.mode == kColToOtf) {
-        tile_store<N>(tile, a.otf_out + otf_tile, kW);
+        tile_store<N, NT>(tile, a.otf_out + otf_tile, kW);
         return;
     }
-    tile_mul<N>(tile, a.otf + otf_tile);
+    tile_mul<N, NT>(tile, a.otf + otf_tile);
     __syncthreads();
-    fft_dit<N, N, +1>(tile, tw);
-    tile_store<N>(tile, base, a.row_stride);
+    fft_dit<N, N, +1, kW, NT>(tile, tw);
+    tile_store<N, NT>(tile, base, a.row_stride);
 }
 
 // ---------------------------------------------------------------------------
@@ -538,9 +538,23 @@ std::vector<float2> twiddles(int n) {
     return t;
 }
 
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Column workgroups: LDS (N x 17 complex) caps long transforms at 1-3 workgroups per CU, so they get 512
+// threads to keep 16+ waves per CU in flight (measured at N = 512: 0.099 -> 0.092 ms per y pass);
+// short ones fit 4+ workgroups of 256 threads.
+template <int N>
+constexpr int col_threads() {
+    return N >= 320 ? 512 : kNT;
+}
+
 template <int N>
 void launch_col(const ColArgs &a, long long blocks, hipStream_t s) {
-    hipLaunchKernelGGL(col_kernel<N>, dim3((unsigned)blocks), dim3(kNT), 0, s, a);
+    constexpr int NT = col_threads<N>();
+    hipLaunchKernelGGL((col_kernel<N, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, a);
 }
 
 void dispatch_col(int n, const ColArgs &a, long long blocks, hipStream_t s) {
@@ -614,10 +628,6 @@ void dispatch_x(int nh, int mode, const XArgs &a, long long rows, hipStream_t s)
     MIL_HIP(hipGetLastError());
 }
 
-int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 }  // namespace
 
