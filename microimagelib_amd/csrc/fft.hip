@@ -163,9 +163,8 @@ __device__ __forceinline__ void dft_small(float2 *v) {
 // One radix-R pass over sub-transforms of length L of an N x 16 tile.
 //   DIF: y_k = w_L^(i*k) * DFT_R(x)[k]      DIT: y = DFT_R( w_L^(i*k) * x_k )
 // Lane mapping: column fastest (16 lanes), then butterfly index.
-template <int N, int R, int L, bool DIT, int SIGN, int W = kW, int NT = kNT>
+template <int N, int R, int L, bool DIT, int SIGN, int W = kW, int NT = kNT, int WP = W + 1>
 __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float2 *__restrict__ tw) {
-    constexpr int WP = W + 1;
     constexpr int M = L / R;            // butterflies per sub-transform
     constexpr int NB = (N / R) * W;     // butterflies in the tile
     constexpr int TWS = N / L;          // table step: w_L = w_N^(N/L)
@@ -207,13 +206,13 @@ struct Radix {
 
 // Barrier contract: the tile must be complete (barrier done) on entry; on return every
 // stage has been followed by a barrier.
-template <int N, int L, int SIGN, int W = kW, int NT = kNT>
+template <int N, int L, int SIGN, int W = kW, int NT = kNT, int WP = W + 1>
 __device__ __forceinline__ void fft_dif(float2 *tile, const float2 *tw) {
     if constexpr (L > 1) {
         constexpr int R = Radix<L>::value;
-        fft_stage<N, R, L, false, SIGN, W, NT>(tile, tw);
+        fft_stage<N, R, L, false, SIGN, W, NT, WP>(tile, tw);
         __syncthreads();
-        fft_dif<N, L / R, SIGN, W, NT>(tile, tw);
+        fft_dif<N, L / R, SIGN, W, NT, WP>(tile, tw);
     }
 }
 template <int N, int L, int SIGN, int W = kW, int NT = kNT>
@@ -241,6 +240,16 @@ struct ColArgs {
     int groups;            // xs / 16
     int mode;
     int reverse;           // walk the tiles last-to-first (ping-pong with the previous kernel: Infinity Cache reuse)
+    // z axis only: column 0 packs the DC and Nyquist x-planes, G = F0 + i*FN (both are spectra of real planes).
+    // Their OTF product needs the Hermitian partner conj(G(-ky, -kz)):
+    const unsigned short *partner;  // tile row holding -ky, per outer index (scrambled y positions)
+    const unsigned short *neg;      // position holding -kz, per scrambled z position
+    const float2 *otf_q;            // kColConv: Q plane [outer][N]
+    float2 *otf_q_out;              // kColToOtf
+    // Copy of column 0, [z][ky]: written by the forward y pass, read by the z kernels for the partner row.
+    // (z-conv works in place, so the partner's column 0 in S may already hold that row's RESULT.)
+    float2 *col0;
+    int col0_stride;  // ny
 };
 
 template <int N, int NT>
@@ -301,7 +310,7 @@ __device__ __forceinline__ void tile_mul(float2 *__restrict__ tile, const float2
     }
 }
 
-template <int N, int NT>
+template <int N, int NT, int MODE>
 __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
     __shared__ float2 tile[N * kWP];
     __shared__ float2 tw[N];
@@ -309,28 +318,115 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
     const int g = bid % a.groups;
     const long long outer = bid / a.groups;
     float2 *base = a.S + outer * a.outer_stride + (long long)g * kW;
+    const long long otf_tile = (long long)bid * N * kW;  // [outer][g][N][16]
+    constexpr bool kZ = (MODE == kColConv || MODE == kColToOtf);
+    const bool packed = kZ && g == 0;  // this tile's column 0 is the packed DC/Nyquist column (wave-uniform)
     for (int k = threadIdx.x; k < N; k += NT) tw[k] = a.tw[k];
     tile_load<N, NT>(tile, base, a.row_stride);
+    if constexpr (kZ) {
+        if (packed) {  // 17th column: column 0 of the row that holds -ky (the LDS padding column carries it)
+            const float2 *pbase = a.col0 + a.partner[outer];
+            for (int k = threadIdx.x; k < N; k += NT) tile[k * kWP + kW] = pbase[(long long)k * a.col0_stride];
+        }
+    }
+    // z-conv: when one batch of registers covers the workgroup's OTF block, request it now so that it arrives
+    // under the forward transform instead of stalling between the two transforms
+    constexpr bool kPrefetch = (MODE == kColConv) && (N * 8 <= NT * kBatch);
+    float4 o[kBatch];
+    if constexpr (kPrefetch) {
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = j * NT + (int)threadIdx.x;
+            if (idx < N * 8) o[j] = *reinterpret_cast<const float4 *>(a.otf + otf_tile + 2 * idx);
+        }
+    }
     __syncthreads();
-    if (a.mode == kColInverse) {
+    if constexpr (MODE == kColInverse) {
         fft_dit<N, N, +1, kW, NT>(tile, tw);
         tile_store<N, NT>(tile, base, a.row_stride);
         return;
     }
-    fft_dif<N, N, -1, kW, NT>(tile, tw);
-    if (a.mode == kColForward) {
+    if constexpr (kZ) {
+        if (packed) fft_dif<N, N, -1, kW + 1, NT, kWP>(tile, tw);  // 17 columns, same LDS stride
+        else fft_dif<N, N, -1, kW, NT>(tile, tw);
+    } else {
+        fft_dif<N, N, -1, kW, NT>(tile, tw);
+    }
+    if constexpr (MODE == kColForward) {
         tile_store<N, NT>(tile, base, a.row_stride);
+        if (g == 0 && a.col0) {  // y pass: outer = z, tile row = scrambled ky
+            for (int k = threadIdx.x; k < N; k += NT) a.col0[outer * N + k] = tile[k * kWP];
+        }
         return;
     }
-    const long long otf_tile = (long long)bid * N * kW;  // [outer][g][N][16]
-    if (a.mode == kColToOtf) {
+    if constexpr (MODE == kColToOtf) {
+        // G = H0 + i*HN for the PSF.  Store P = (H0+HN)/2 in the column-0 slot and Q = (H0-HN)/2 aside, so that the
+        // product of a packed column is  P*G + Q*conj(G(-k))  (two complex multiplies, no un-mixing at run time).
+        if (packed) {
+            float2 pv[(N + NT - 1) / NT], qv[(N + NT - 1) / NT];
+#pragma unroll
+            for (int i = 0; i < (N + NT - 1) / NT; ++i) {
+                const int k = i * NT + (int)threadIdx.x;
+                if (k < N) {
+                    const float2 gk = tile[k * kWP], gp = tile[a.neg[k] * kWP + kW];
+                    const float2 gb = make_float2(gp.x, -gp.y);                                   // conj(G(-k))
+                    const float2 h0 = make_float2(0.5f * (gk.x + gb.x), 0.5f * (gk.y + gb.y));    // (G + Gb)/2
+                    const float2 hn = make_float2(0.5f * (gk.y - gb.y), -0.5f * (gk.x - gb.x));   // (G - Gb)/(2i)
+                    pv[i] = make_float2(0.5f * (h0.x + hn.x), 0.5f * (h0.y + hn.y));
+                    qv[i] = make_float2(0.5f * (h0.x - hn.x), 0.5f * (h0.y - hn.y));
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < (N + NT - 1) / NT; ++i) {
+                const int k = i * NT + (int)threadIdx.x;
+                if (k < N) {
+                    tile[k * kWP] = pv[i];
+                    a.otf_q_out[outer * N + k] = qv[i];
+                }
+            }
+            __syncthreads();
+        }
         tile_store<N, NT>(tile, a.otf_out + otf_tile, kW);
         return;
     }
-    tile_mul<N, NT>(tile, a.otf + otf_tile);
-    __syncthreads();
-    fft_dit<N, N, +1, kW, NT>(tile, tw);
-    tile_store<N, NT>(tile, base, a.row_stride);
+    if constexpr (MODE == kColConv) {
+        float2 keep[(N + NT - 1) / NT];  // packed column: Q * conj(G(-k)), added after the plain product
+        if (packed) {
+#pragma unroll
+            for (int i = 0; i < (N + NT - 1) / NT; ++i) {
+                const int k = i * NT + (int)threadIdx.x;
+                if (k < N) {
+                    const float2 gp = tile[a.neg[k] * kWP + kW];
+                    keep[i] = c_mul(a.otf_q[outer * N + k], make_float2(gp.x, -gp.y));
+                }
+            }
+        }
+        if constexpr (kPrefetch) {
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int idx = j * NT + (int)threadIdx.x;
+                if (idx < N * 8) {
+                    float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
+                    q[0] = c_mul(q[0], make_float2(o[j].x, o[j].y));
+                    q[1] = c_mul(q[1], make_float2(o[j].z, o[j].w));
+                }
+            }
+        } else {
+            tile_mul<N, NT>(tile, a.otf + otf_tile);
+        }
+        if (packed) {
+            __syncthreads();  // column 0 now holds P*G
+#pragma unroll
+            for (int i = 0; i < (N + NT - 1) / NT; ++i) {
+                const int k = i * NT + (int)threadIdx.x;
+                if (k < N) tile[k * kWP] = c_add(tile[k * kWP], keep[i]);
+            }
+        }
+        __syncthreads();
+        fft_dit<N, N, +1, kW, NT>(tile, tw);
+        tile_store<N, NT>(tile, base, a.row_stride);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -352,7 +448,7 @@ struct XArgs {
 template <int NH, int MODE, int RB>
 __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
     constexpr int NX = 2 * NH;
-    constexpr int XS = ((NH + 1 + kW - 1) / kW) * kW;
+    constexpr int XS = ((NH + kW - 1) / kW) * kW + kW;  // row pitch: the columns plus one never-touched group (see ConvPlan)
     constexpr int WP = RB + 1;
     __shared__ float2 tile[NH * WP];
     __shared__ float2 tw[NH];            // w_NH^k = w_NX^(2k)
@@ -365,8 +461,9 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
     }
     if constexpr (MODE != kXForward) {
         // ---- spectrum rows -> packed half-length complex sequence Z' in tile[k][row].
-        // Spectrum columns are stored in mirrored pairs: column 2j = X[j], column 2j+1 = X[NH-j]
-        // (j < NH/2), column NH = X[NH/2]; one float4 is exactly the pair the Hermitian fold needs.
+        // Spectrum columns are stored in mirrored pairs: column 2j = X[j], column 2j+1 = X[NH-j] (1 <= j < NH/2), so one
+        // float4 is exactly the pair the Hermitian fold needs.  Column 0 packs the two REAL row values (X[0], X[NH]) into
+        // one complex number and column 1 holds the self-paired X[NH/2]: NH columns in all, no padding column.
         {
             constexpr int TOTAL = RB * (NH / 2);
             const float2 *src = a.S + row0 * XS;
@@ -389,17 +486,17 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
                     if (idx < TOTAL) {
                         const int row = idx / (NH / 2), k = idx % (NH / 2);
                         float2 x = make_float2(v[j].x, v[j].y), y = make_float2(v[j].z, v[j].w);
-                        if (k == 0) x.y = 0.f, y.y = 0.f;  // C2R ignores the imaginary parts of DC and Nyquist
+                        if (k == 0) {  // packed column: X[0] = (re, 0), X[NH] = (im, 0); column 1 = X[NH/2]
+                            tile[(NH / 2) * WP + row] = make_float2(2.f * y.x, -2.f * y.y);  // Z'[NH/2] = 2 conj(X[NH/2])
+                            y = make_float2(x.y, 0.f);
+                            x.y = 0.f;
+                        }
                         const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
                         const float ux = w[j].x * dx + w[j].y * dy, uy = w[j].x * dy - w[j].y * dx;
                         tile[k * WP + row] = make_float2(sx - uy, sy + ux);
                         if (k != 0) tile[(NH - k) * WP + row] = make_float2(sx + uy, ux - sy);
                     }
                 }
-            }
-            if (threadIdx.x < RB) {  // self-paired middle column: Z'[NH/2] = 2 conj(X[NH/2])
-                const float2 m = src[(long long)threadIdx.x * XS + NH];
-                tile[(NH / 2) * WP + threadIdx.x] = make_float2(2.f * m.x, -2.f * m.y);
             }
         }
         __syncthreads();
@@ -472,12 +569,12 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
             const float2 w = a.tw[k];
             const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
             const float tx = w.x * dx - w.y * dy, ty = w.x * dy + w.y * dx;
-            *reinterpret_cast<float4 *>(dst + (long long)row * XS + 2 * k) =
-                make_float4(0.5f * (sx + ty), 0.5f * (sy - tx), 0.5f * (sx - ty), 0.5f * (-sy - tx));
-        }
-        if (threadIdx.x < RB) {  // X[NH/2] = conj(Z[NH/2])
-            const float2 m = tile[(NH / 2) * WP + threadIdx.x];
-            dst[(long long)threadIdx.x * XS + NH] = make_float2(m.x, -m.y);
+            float4 o = make_float4(0.5f * (sx + ty), 0.5f * (sy - tx), 0.5f * (sx - ty), 0.5f * (-sy - tx));
+            if (k == 0) {  // (X[0], X[NH]) are real: pack them; X[NH/2] = conj(Z[NH/2]) rides in column 1
+                const float2 m = tile[(NH / 2) * WP + row];
+                o = make_float4(o.x, o.z, m.x, -m.y);
+            }
+            *reinterpret_cast<float4 *>(dst + (long long)row * XS + 2 * k) = o;
         }
     }
 }
@@ -486,10 +583,11 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
 // test aid: private OTF order -> natural order
 // ---------------------------------------------------------------------------
 __global__ void otf_to_natural_kernel(float2 *__restrict__ nat, const float2 *__restrict__ otf,
-                                      const unsigned short *__restrict__ freq_y,
+                                      const float2 *__restrict__ otf_q, const unsigned short *__restrict__ freq_y,
                                       const unsigned short *__restrict__ freq_z, int nxh1, int ny, int nz, int groups) {
     // one thread per private element (ky_s, g, kz_s, c)
     const long long total = (long long)ny * groups * nz * kW;
+    const int nh = nxh1 - 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % kW);
         long long r = i / kW;
@@ -497,10 +595,19 @@ __global__ void otf_to_natural_kernel(float2 *__restrict__ nat, const float2 *__
         r /= nz;
         const int g = (int)(r % groups);
         const int py = (int)(r / groups);
-        const int col = g * kW + c, nh = nxh1 - 1;  // mirrored-pair column order of the x pass
-        if (col > nh) continue;
-        const int kx = (col == nh) ? nh / 2 : ((col & 1) ? nh - (col >> 1) : (col >> 1));
-        nat[((long long)freq_z[pz] * ny + freq_y[py]) * nxh1 + kx] = otf[i];
+        const int col = g * kW + c;  // packed / mirrored-pair column order of the x pass
+        if (col >= nh) continue;
+        float2 *row = nat + ((long long)freq_z[pz] * ny + freq_y[py]) * nxh1;
+        const float2 v = otf[i];
+        if (col == 0) {  // P = (H0+HN)/2, Q = (H0-HN)/2
+            const float2 q = otf_q[(long long)py * nz + pz];
+            row[0] = make_float2(v.x + q.x, v.y + q.y);
+            row[nh] = make_float2(v.x - q.x, v.y - q.y);
+        } else if (col == 1) {
+            row[nh / 2] = v;
+        } else {
+            row[(col & 1) ? nh - (col >> 1) : (col >> 1)] = v;
+        }
     }
 }
 
@@ -554,7 +661,13 @@ constexpr int col_threads() {
 template <int N>
 void launch_col(const ColArgs &a, long long blocks, hipStream_t s) {
     constexpr int NT = col_threads<N>();
-    hipLaunchKernelGGL((col_kernel<N, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, a);
+    const dim3 grid((unsigned)blocks), block(NT);
+    switch (a.mode) {
+        case kColForward: hipLaunchKernelGGL((col_kernel<N, NT, kColForward>), grid, block, 0, s, a); break;
+        case kColInverse: hipLaunchKernelGGL((col_kernel<N, NT, kColInverse>), grid, block, 0, s, a); break;
+        case kColConv: hipLaunchKernelGGL((col_kernel<N, NT, kColConv>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((col_kernel<N, NT, kColToOtf>), grid, block, 0, s, a); break;
+    }
 }
 
 void dispatch_col(int n, const ColArgs &a, long long blocks, hipStream_t s) {
@@ -647,7 +760,11 @@ bool ConvPlan::supported(Dims b) {
 ConvPlan::ConvPlan(Dims box) : box_(box) {
     if (!supported(box)) throw Error(-1, "ConvPlan: unsupported box (need powers of two or multiples of 64, 16..1024, x up to 2048)");
     const int nx = (int)box.nx, ny = (int)box.ny, nz = (int)box.nz, nh = nx / 2;
-    xs_ = ((nh + 1 + kW - 1) / kW) * kW;
+    xs_ = ((nh + kW - 1) / kW) * kW;
+    // Row pitch = columns + 16: nx/2 is a power of two for the common boxes, and power-of-two row / plane strides make the
+    // strided y and z passes camp on a few HBM channels (measured: z-conv 5 % slower at pitch 256 than at 272).
+    pitch_ = xs_ + kW;
+    col0_.alloc((size_t)box.ny * box.nz);
     ablate_ = env_int("MIL_FX_ABLATE", 0);
     upload(tw_x_, twiddles(nx));
     upload(tw_y_, twiddles(ny));
@@ -659,6 +776,16 @@ ConvPlan::ConvPlan(Dims box) : box_(box) {
     upload(pos_x_, p);
     upload(freq_y_, fy);
     upload(freq_z_, fz);
+    // position of the negated frequency, per position (Hermitian partner of the packed DC/Nyquist column)
+    auto negated = [](const std::vector<unsigned short> &freq) {
+        const int n = (int)freq.size();
+        std::vector<unsigned short> pos((size_t)n), neg((size_t)n);
+        for (int q = 0; q < n; ++q) pos[freq[(size_t)q]] = (unsigned short)q;
+        for (int q = 0; q < n; ++q) neg[(size_t)q] = pos[(size_t)((n - freq[(size_t)q]) % n)];
+        return neg;
+    };
+    upload(neg_y_, negated(fy));
+    upload(neg_z_, negated(fz));
 }
 
 void ConvPlan::x_pass(XMode mode, float2 *S, const float *rin, float *rout, const float *M, float eps,
@@ -675,8 +802,10 @@ void ConvPlan::x_pass(XMode mode, float2 *S, const float *rin, float *rout, cons
 void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s, bool reverse) const {
     ColArgs a;
     a.S = S; a.otf = nullptr; a.otf_out = nullptr; a.tw = tw_y_.get();
-    a.row_stride = xs_;
-    a.outer_stride = (long long)box_.ny * xs_;
+    a.partner = nullptr; a.neg = nullptr; a.otf_q = nullptr; a.otf_q_out = nullptr;
+    a.col0 = inverse ? nullptr : col0_.get(); a.col0_stride = (int)box_.ny;
+    a.row_stride = pitch_;
+    a.outer_stride = (long long)box_.ny * pitch_;
     a.groups = xs_ / kW;
     a.mode = inverse ? kColInverse : kColForward;
     a.reverse = reverse ? 1 : 0;
@@ -686,8 +815,11 @@ void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s, bool reverse) cons
 void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s, bool reverse) const {
     ColArgs a;
     a.S = S; a.otf = otf; a.otf_out = nullptr; a.tw = tw_z_.get();
-    a.row_stride = (long long)box_.ny * xs_;
-    a.outer_stride = xs_;
+    a.partner = neg_y_.get(); a.neg = neg_z_.get();
+    a.otf_q = otf + (size_t)xs_ * box_.ny * box_.nz; a.otf_q_out = nullptr;
+    a.col0 = col0_.get(); a.col0_stride = (int)box_.ny;
+    a.row_stride = (long long)box_.ny * pitch_;
+    a.outer_stride = pitch_;
     a.groups = xs_ / kW;
     a.mode = kColConv;
     a.reverse = reverse ? 1 : 0;
@@ -697,8 +829,11 @@ void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s, bool reverse)
 void ConvPlan::z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) const {
     ColArgs a;
     a.S = const_cast<float2 *>(S); a.otf = nullptr; a.otf_out = otf; a.tw = tw_z_.get();
-    a.row_stride = (long long)box_.ny * xs_;
-    a.outer_stride = xs_;
+    a.partner = neg_y_.get(); a.neg = neg_z_.get();
+    a.otf_q = nullptr; a.otf_q_out = otf + (size_t)xs_ * box_.ny * box_.nz;
+    a.col0 = col0_.get(); a.col0_stride = (int)box_.ny;
+    a.row_stride = (long long)box_.ny * pitch_;
+    a.outer_stride = pitch_;
     a.groups = xs_ / kW;
     a.mode = kColToOtf;
     a.reverse = 0;
@@ -707,8 +842,9 @@ void ConvPlan::z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) con
 
 void ConvPlan::otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const {
     const int nxh1 = (int)box_.nx / 2 + 1;
-    hipLaunchKernelGGL(otf_to_natural_kernel, dim3(2048), dim3(256), 0, s, natural, otf, freq_y_.get(), freq_z_.get(),
-                       nxh1, (int)box_.ny, (int)box_.nz, xs_ / kW);
+    hipLaunchKernelGGL(otf_to_natural_kernel, dim3(2048), dim3(256), 0, s, natural, otf,
+                       otf + (size_t)xs_ * box_.ny * box_.nz, freq_y_.get(), freq_z_.get(), nxh1, (int)box_.ny,
+                       (int)box_.nz, xs_ / kW);
     MIL_HIP(hipGetLastError());
 }
 

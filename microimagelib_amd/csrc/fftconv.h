@@ -10,10 +10,11 @@
 //   y pass   128-byte column tiles, in place
 //   z conv   forward z transform, complex OTF product, inverse z transform in one kernel, in place
 //
-// One view update = 8 launches moving 18 C' + 3 R bytes instead of ~26 C + 12 R (C' = padded
-// half spectrum, R = real volume).  Spectra live in a PRIVATE layout (y and z in the digit-reversed
-// order the in-place transforms leave them in, x padded to a multiple of 16 columns, OTFs tiled per
-// z-conv workgroup); nothing outside this module depends on it.  Boxes: every size snapTransformSize
+// One view update = 8 launches moving 18 C' + 3 R bytes instead of ~26 C + 12 R (C' = packed half
+// spectrum = R bytes, R = real volume).  Spectra live in a PRIVATE layout: nx/2 complex columns (the real
+// DC and Nyquist row values share column 0, mirrored pairs (X[j], X[nx/2-j]) after that), y and z in the
+// digit-reversed order the in-place transforms leave them in, OTFs tiled per z-conv workgroup plus a small
+// "Q" plane for the packed column; nothing outside this module depends on it.  Boxes: every size snapTransformSize
 // produces up to 1024 per axis (powers of two from 16, and the multiples of 64 from 192: radices
 // 8/4/2 plus 3, 5, 7, 11, 13), x also 2048; anything else uses the rocFFT path in decon.cpp.
 #pragma once
@@ -37,7 +38,9 @@ public:
     explicit ConvPlan(Dims box);
     Dims box() const { return box_; }
     int xs() const { return xs_; }  // padded spectral x extent (complex columns)
-    size_t spectrum_count() const { return (size_t)xs_ * box_.ny * box_.nz; }
+    // complex64 elements of a spectrum / OTF buffer: xs*ny*nz tile elements + the ny*nz "Q" plane an OTF
+    // carries for the packed DC/Nyquist column (spectra simply do not use the tail)
+    size_t spectrum_count() const { return (size_t)pitch_ * box_.ny * box_.nz + (size_t)box_.ny * box_.nz; }
 
     // x pass over all ny*nz rows.  S: private spectrum.  Arguments by mode:
     //   kXForward     rin (real in)                      -> S
@@ -57,11 +60,14 @@ public:
 
 private:
     Dims box_;
-    int xs_ = 0;
+    int xs_ = 0;     // spectral columns (multiple of 16)
+    int pitch_ = 0;  // row pitch of a spectrum in complex elements (xs_ + 16)
+    mutable DeviceBuffer<float2> col0_;  // [z][ky] copy of the packed column, forward y pass -> z kernels
     int ablate_ = 0;   // MIL_FX_ABLATE: timing experiments only, results are wrong when non-zero
     DeviceBuffer<float2> tw_x_, tw_y_, tw_z_;   // exp(-2*pi*i*k/n), k in [0, n)
     DeviceBuffer<unsigned short> pos_x_;        // position of element n after digit reversal, n in [0, nx/2)
     DeviceBuffer<unsigned short> freq_y_, freq_z_;  // frequency held at scrambled position p
+    DeviceBuffer<unsigned short> neg_y_, neg_z_;    // position holding the negated frequency of position p
 };
 
 // Host-side tables (also used by the CPU tests through the C ABI).
