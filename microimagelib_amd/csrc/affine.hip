@@ -56,10 +56,11 @@ __device__ __forceinline__ Tap make_tap(float t, int n) {
     Tap p;
     p.w1 = b - f;
     p.w0 = 1.0f - p.w1;
-    int i = (int)f;
-    int j = i + 1;
-    p.i0 = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-    p.i1 = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+    // Only called for t inside the validity window, so i = floor(t - 0.5) lies in [-1, n-1]: the edge clamp of the
+    // reference's texture fetch reduces to one max and one min.
+    const int i = (int)f;
+    p.i0 = i < 0 ? 0 : i;
+    p.i1 = i + 1 > n - 1 ? n - 1 : i + 1;
     return p;
 }
 
@@ -151,8 +152,9 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
             if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
                 sv = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
             const float tv = *tp;
-            ss += (double)sv * (double)sv;
-            st += (double)sv * (double)tv;
+            // float x float is exact in double, so the fused form rounds exactly like multiply-then-add
+            ss = __builtin_fma((double)sv, (double)sv, ss);
+            st = __builtin_fma((double)sv, (double)tv, st);
         }
     }
     ss = wave_sum(ss);
