@@ -117,3 +117,34 @@ def test_16bit_output_and_const_init(tmp_path, which):
     want = do.decon_singleview(img16, psf, 3, const_init=True)
     got = api.readtifstack(str(out))
     assert np.max(np.abs(got - np.floor(want))) <= 1.0  # truncation of values that differ by rounding
+
+
+def test_spimFusion_cli(tmp_path, which):
+    """spimFusion end to end: anisotropic view A (z resampled x2), view B rotated -90 deg about Y, 3-DOF
+    registration, joint RL.  Checked against the same chain through the Python API (libapi.so calls in the same
+    order, src/spim_fusion.cpp:563-672)."""
+    from microimagelib_amd import api
+    exe = _need("spimFusion", which)
+    psf_a = do.gaussian_psf((7, 7, 7), (1.5, 1.0, 1.0))
+    psf_b = do.gaussian_psf((7, 7, 7), (1.0, 1.0, 1.5))
+    a_in = do.synthetic_view((16, 32, 32), psf_a, seed=1, noise_seed=2, n_blobs=10)   # z sampled 2x coarser
+    b_in = do.synthetic_view((32, 32, 16), psf_b, seed=1, noise_seed=3, n_blobs=10)   # x sampled 2x coarser
+    for name, arr in (("a", a_in), ("b", b_in), ("pa", psf_a), ("pb", psf_b)):
+        api.writetifstack(str(tmp_path / f"{name}.tif"), arr, 32)
+    out, otmx = tmp_path / "decon.tif", tmp_path / "out.tmx"
+    r = subprocess.run([exe, "-i1", str(tmp_path / "a.tif"), "-i2", str(tmp_path / "b.tif"), "-fp1",
+                        str(tmp_path / "pa.tif"), "-fp2", str(tmp_path / "pb.tif"), "-o", str(out), "-pxx1", "1", "-pxy1",
+                        "1", "-pxz1", "2", "-pxx2", "2", "-pxy2", "1", "-pxz2", "1", "-imgrot", "-1", "-regc", "2", "-affm",
+                        "1", "-itreg", "200", "-otmx", str(otmx), "-it", "3", "-bit", "32", "-verbOFF"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = api.readtifstack(str(out))
+    # same chain through the API
+    a = api.imresize3d(a_in, (32, 32, 32))
+    b = api.imresize3d(api.imoperation3D(b_in, 2), (32, 32, 32))
+    b_reg, tmx, _ = api.reg3d(a, b, reg_choice=2, aff_method=1, it_limit=200)
+    want, _ = api.decon_dualview(a, b_reg, psf_a, psf_b, 3)
+    assert got.shape == want.shape == (32, 32, 32)
+    assert np.array_equal(got, want)
+    m_file = np.array([float(v) for v in open(otmx).read().split()[:12]], dtype=np.float32)
+    assert np.allclose(m_file, tmx, atol=1e-5)
