@@ -12,6 +12,10 @@ FLAGS = {
     "deconSingleView": ["-i", "-fp", "-o", "-bp", "-it", "-gm", "-dev", "-cON", "-cOFF", "-bit", "-verbON", "-verbOFF", "-log"],
     "deconDualView": ["-i1", "-i2", "-fp1", "-fp2", "-o", "-bp1", "-bp2", "-it", "-cON", "-cOFF", "-gm", "-dev", "-bit",
                       "-verbON", "-verbOFF", "-log"],
+    # src/spim_fusion.cpp:22-79
+    "spimFusion": ["-i1", "-i2", "-fp1", "-fp2", "-o", "-pxx1", "-pxy1", "-pxz1", "-pxx2", "-pxy2", "-pxz2", "-imgrot",
+                   "-oreg1", "-oreg2", "-itmx", "-otmx", "-regc", "-affm", "-ftol", "-itreg", "-bp1", "-bp2", "-it", "-cON",
+                   "-cOFF", "-gm", "-dev", "-bit", "-verbON", "-verbOFF", "-log"],
     "reg3D": ["-t", "-s", "-o", "-itmx", "-otmx", "-regc", "-affm", "-ftol", "-it", "-gm", "-dev", "-bit", "-verbON",
               "-verbOFF", "-log"],
 }
