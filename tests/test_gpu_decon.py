@@ -219,3 +219,14 @@ def test_full_size_properties(dev):
     eng.sync()
     assert torch.equal(first, E)  # bitwise reproducible run to run
     eng.close()
+
+
+@pytest.mark.parametrize("shape", [(70, 150, 200), (33, 130, 300), (12, 20, 500)])
+def test_api_ragged_sizes_snap_to_odd_radix_boxes(api, shape):
+    """Image extents that snapTransformSize rounds to 64*k boxes (128x192x256, 64x192x320, 16x32x512): edge-replicate
+    pad, odd-radix transforms, RL, centred crop -- against the oracle."""
+    psf = do.gaussian_psf((11, 11, 11), (2.0, 1.3, 1.3))
+    img = do.synthetic_view(shape, psf, seed=11, noise_seed=12, n_blobs=15)
+    out, rec = api.decon_singleview(img, psf, 5)
+    assert rec[0] == 1
+    assert rel_err(out, do.decon_singleview(img, psf, 5)) < RTOL

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""RL iterations/s of both transform backends over a range of FFT boxes (incl. the 64*k sizes of
+snapTransformSize), and their agreement on the result.  Evidence for DESIGN.md, not a test."""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from microimagelib_amd import device as mdev
+
+def gaussian_psf(shape, sig):
+    g = [np.exp(-0.5 * ((np.arange(s) - s // 2) / sg) ** 2) for s, sg in zip(shape, sig)]
+    return (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
+
+BOXES = [(64, 64, 64), (128, 128, 128), (128, 256, 256), (256, 256, 256), (256, 512, 512), (512, 512, 512),
+         (192, 192, 192), (256, 384, 384), (128, 320, 448), (256, 576, 640), (512, 1024, 1024)]
+iters = 10
+rows = []
+for box in BOXES:
+    g = torch.Generator(device="cuda").manual_seed(1)
+    img = torch.rand(box, device="cuda", generator=g) * 1000 + 10
+    psf = torch.from_numpy(gaussian_psf((31, 31, 31), (3.0, 1.5, 1.5))).cuda()
+    res = {}
+    for name, backend in (("fused", 2), ("rocfft", 1)):
+        eng = mdev.DeconEngine(box, backend=backend)
+        otf, bp = eng.gen_otf(psf), eng.gen_otf(psf, flip=True)
+        A = img.clone(); E = torch.empty_like(A)
+        eng.init_single(A, E); eng.run_single(E, A, otf, bp, 2); eng.sync()
+        eng.init_single(A, E); eng.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run_single(E, A, otf, bp, iters); eng.sync()
+        dt = time.perf_counter() - t0
+        res[name] = (iters / dt, E.clone())
+        eng.close()
+        del otf, bp, A, E
+    a, b = res["fused"][1], res["rocfft"][1]
+    rel = float(((a - b).abs() / torch.clamp(b.abs(), min=float(b.abs().mean()))).max())
+    vox = box[0] * box[1] * box[2]
+    rows.append({"box_zyx": box, "fused_it_s": round(res["fused"][0], 1), "rocfft_it_s": round(res["rocfft"][0], 1),
+                 "speedup": round(res["fused"][0] / res["rocfft"][0], 2),
+                 "fused_GB_s_algorithmic": round(res["fused"][0] * (21 * 4 * vox) / 1e9, 0), "max_rel_diff": rel})
+    print(rows[-1], flush=True)
+    del res, a, b, img
+    torch.cuda.empty_cache()
+json.dump(rows, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "bench_sizes.json"), "w"), indent=1)
