@@ -238,43 +238,50 @@ void DeconEngine::init_dual(float *A, float *B, float *E, bool const_init) {
 
 // Fused backend: the estimate's x-spectrum is carried from one view update to the next, so a
 // view update is  y, z-conv(OTF), y^-1, x^-1 | ratio | x, y, z-conv(OTF_bp), y^-1, x^-1 | update | x.
-void DeconEngine::run_fused(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp,
-                            int views, int iters) {
-    if (iters <= 0) return;
-    float2 *S = S_.get();
-    // x and y kernels walk the volume in z order; each one runs opposite to its predecessor so that it
-    // starts on the slabs written last (Infinity Cache hits instead of HBM reads).  `dir` is the
-    // direction of the most recent z-ordered kernel.
+//
+// x and y kernels walk the volume in z order; each one runs opposite to its predecessor so that it
+// starts on the slabs written last (Infinity Cache hits instead of HBM reads).  The direction flips
+// four times per view update, so every iteration starts in the same state.
+void DeconEngine::enqueue_iteration(float *E, const float *const *M, const float2 *const *otf,
+                                    const float2 *const *otf_bp, int views, bool last_iteration) {
     static const bool pingpong = !(getenv("MIL_FX_PINGPONG") && !strcmp(getenv("MIL_FX_PINGPONG"), "0"));
-    bool dir = false;
+    float2 *S = S_.get();
+    bool dir = false;  // direction of the most recent z-ordered kernel (the x pass that produced S)
     auto next_dir = [&] { dir = pingpong ? !dir : false; return dir; };
-    plan_->x_pass(fx::kXForward, S, E, nullptr, nullptr, 0.f, stream_, dir);
-    for (int it = 0; it < iters; ++it) {
-        for (int v = 0; v < views; ++v) {
-            const bool last = (it == iters - 1) && (v == views - 1);
-            for (int half = 0; half < 2; ++half) {
-                timers[kTimeFft].begin(stream_);
-                plan_->y_pass(S, false, stream_, next_dir());
-                timers[kTimeFft].end(stream_);
-                timers[kTimeCmul].begin(stream_);
-                plan_->z_conv(S, half == 0 ? otf[v] : otf_bp[v], stream_, false);  // :3406-3408 / :3411-3413
-                timers[kTimeCmul].end(stream_);
-                timers[kTimeFft].begin(stream_);
-                plan_->y_pass(S, true, stream_, dir);  // z_conv touched every slab: keep the direction
-                timers[kTimeFft].end(stream_);
-                if (half == 0) {
-                    timers[kTimeRatio].begin(stream_);
-                    plan_->x_pass(fx::kXRatio, S, nullptr, nullptr, M[v], 0.f, stream_, next_dir());  // :3409
-                    timers[kTimeRatio].end(stream_);
-                } else {
-                    timers[kTimeUpdate].begin(stream_);
-                    plan_->x_pass(last ? fx::kXUpdateLast : fx::kXUpdate, S, nullptr, E, nullptr, kSmallValue,
-                                  stream_, next_dir());  // :3414-3415
-                    timers[kTimeUpdate].end(stream_);
-                }
+    for (int v = 0; v < views; ++v) {
+        const bool last = last_iteration && (v == views - 1);
+        for (int half = 0; half < 2; ++half) {
+            timers[kTimeFft].begin(stream_);
+            plan_->y_pass(S, false, stream_, next_dir());
+            timers[kTimeFft].end(stream_);
+            timers[kTimeCmul].begin(stream_);
+            plan_->z_conv(S, half == 0 ? otf[v] : otf_bp[v], stream_, false);  // :3406-3408 / :3411-3413
+            timers[kTimeCmul].end(stream_);
+            timers[kTimeFft].begin(stream_);
+            plan_->y_pass(S, true, stream_, dir);  // z_conv touched every slab: keep the direction
+            timers[kTimeFft].end(stream_);
+            if (half == 0) {
+                timers[kTimeRatio].begin(stream_);
+                plan_->x_pass(fx::kXRatio, S, nullptr, nullptr, M[v], 0.f, stream_, next_dir());  // :3409
+                timers[kTimeRatio].end(stream_);
+            } else {
+                timers[kTimeUpdate].begin(stream_);
+                plan_->x_pass(last ? fx::kXUpdateLast : fx::kXUpdate, S, nullptr, E, nullptr, kSmallValue, stream_,
+                              next_dir());  // :3414-3415
+                timers[kTimeUpdate].end(stream_);
             }
         }
     }
+}
+
+void DeconEngine::run_fused(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp,
+                            int views, int iters) {
+    if (iters <= 0) return;
+    plan_->x_pass(fx::kXForward, S_.get(), E, nullptr, nullptr, 0.f, stream_, false);
+    // Plain asynchronous launches.  Replaying one captured iteration as a HIP graph was measured and dropped:
+    // 918 vs 915 it/s at 512x512x256 (kernels of 90-170 us hide the launches anyway) and SLOWER on small boxes
+    // (64^3: 19.9k vs 27.1k it/s -- a replay costs more than eight queued launches).
+    for (int it = 0; it < iters; ++it) enqueue_iteration(E, M, otf, otf_bp, views, it == iters - 1);
 }
 
 void DeconEngine::view_update(float *E, const float *M, const float2 *otf, const float2 *otf_bp) {

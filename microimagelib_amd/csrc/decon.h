@@ -99,6 +99,9 @@ private:
     fx::ConvPlan *plan_ = nullptr;  // fused backend
     void run_fused(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp, int views,
                    int iters);
+    void enqueue_iteration(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp,
+                           int views, bool last_iteration);
+
     DeviceBuffer<float> T_;
     DeviceBuffer<float2> S_;
     k::ReduceWorkspace red_;
