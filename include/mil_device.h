@@ -98,6 +98,10 @@ int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records,
                      void *stream);
 
+/* regChoice 4 pre-registration: 2-D MIP shift search, src/api_reg.cpp:448-497 + reg2d_shiftalign1 / X1
+ * (src/api_subfunc.cu:1860-2120).  shift3 = {x, y, z} translation in voxels (host). */
+int mil_reg3d_mip_shift(float *shift3, const float *d_img1, const float *d_img2, int nx, int ny, int nz, void *stream);
+
 /* ---- host-side pieces of the path (no GPU needed) --------------------------- */
 /* powell(), src/api_powell.c:305-360.  0-based: p[n]; xi row-major with leading dimension ld,
  * column j = direction j.  f is called with a 0-based parameter vector. */

@@ -85,6 +85,7 @@ SIGNATURES = {
     "mil_corr_sums": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, c_double_p, C.c_void_p]),
     "mil_reg3d_affine": (C.c_int, [C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, C.c_void_p]),
+    "mil_reg3d_mip_shift": (C.c_int, [c_float_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mil_powell": (C.c_int, [c_float_p, c_float_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), c_float_p,
                              COST_FN, C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "mil_p2matrix": (None, [c_float_p, c_float_p]),

@@ -193,9 +193,12 @@ class FusionPipeline:
         self.estimate = torch.empty(self.shape, dtype=torch.float32, device=psf_a.device)
 
     def reg_fn(self, target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
-        """reg3d on device volumes: regChoice 0 (apply / copy) and 2 (affine); the coarse pre-registrations
-        (1, 3, 4) are not on the hot path and fall back to plain affine here."""
+        """reg3d on device volumes: regChoice 0 (apply / copy), 2 (affine) and 4 (2-D MIP shift search, then
+        affine from that translation: src/api_reg.cpp:448-497); the phasor variants (1, 3) fall back to plain affine."""
         method = 0 if reg_choice == 0 else aff_method
+        if reg_choice == 4:
+            sx, sy, sz = self._mdev.reg3d_mip_shift(target, source)
+            i_tmx, input_tmx = np.array([1, 0, 0, sx, 0, 1, 0, sy, 0, 0, 1, sz], dtype=np.float32), True
         return self._mdev.reg3d_affine(target, source, aff_method=method, i_tmx=i_tmx, flag_tmx=bool(input_tmx),
                                        ftol=ftol, it_limit=it_limit)
 

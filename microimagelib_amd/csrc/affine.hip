@@ -128,6 +128,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // the two reductions the reference does in separate launches (sumgpu1D, src/api_subfunc.cu:970-971).
 // Each workgroup owns a 64 x 4 x kCorrZ target tile; float64 accumulators per lane, DPP/shuffle
 // wave reduction, LDS across the 4 waves, one (ss, st) partial per workgroup.
+//
+// FLOAT_PRODUCTS: the 2-D variant of the reference (corr2Dkernel, include/cukernel.cuh:575-597) forms t*t and s*t in
+// float32 and sums those in float64 on the host (src/api_subfunc.cu:1027-1030); a 2-D image is a one-plane volume here.
+template <bool FLOAT_PRODUCTS>
 __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__restrict__ tgt,
                                                            const float *__restrict__ src, AffineArgs a,
                                                            double *__restrict__ partials, int nblocks) {
@@ -152,9 +156,15 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
             if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
                 sv = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
             const float tv = *tp;
-            // float x float is exact in double, so the fused form rounds exactly like multiply-then-add
-            ss = __builtin_fma((double)sv, (double)sv, ss);
-            st = __builtin_fma((double)sv, (double)tv, st);
+            if (FLOAT_PRODUCTS) {
+                const float q = sv * sv, c = tv * sv;
+                ss += (double)q;
+                st += (double)c;
+            } else {
+                // float x float is exact in double, so the fused form rounds exactly like multiply-then-add
+                ss = __builtin_fma((double)sv, (double)sv, ss);
+                st = __builtin_fma((double)sv, (double)tv, st);
+            }
         }
     }
     ss = wave_sum(ss);
@@ -234,14 +244,19 @@ CorrWorkspace::~CorrWorkspace() {
 }
 
 void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
-                     CorrWorkspace &ws, hipStream_t s) {
+                     CorrWorkspace &ws, hipStream_t s, bool float_products) {
     AffineArgs a = make_args(t_dims, s_dims, m);
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
     if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
-    hipLaunchKernelGGL(corr_kernel, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(), (int)nblocks);
+    if (float_products)
+        hipLaunchKernelGGL(corr_kernel<true>, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
+                           (int)nblocks);
+    else
+        hipLaunchKernelGGL(corr_kernel<false>, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
+                           (int)nblocks);
     MIL_HIP(hipGetLastError());
     // the final pass writes (ss, st) straight into pinned host memory: no copy node, one stream sync per evaluation
     hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(kFinalThreads), 0, s, ws.partials.get(), (int)nblocks, ws.host);
@@ -249,8 +264,8 @@ void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_
 }
 
 void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
-                    CorrWorkspace &ws, hipStream_t s, double *ss, double *st) {
-    corr_sums_async(target, src, t_dims, s_dims, m, ws, s);
+                    CorrWorkspace &ws, hipStream_t s, double *ss, double *st, bool float_products) {
+    corr_sums_async(target, src, t_dims, s_dims, m, ws, s, float_products);
     MIL_HIP(hipStreamSynchronize(s));
     *ss = ws.host[0];
     *st = ws.host[1];

@@ -64,10 +64,9 @@ extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, un
         printf("\n*** Wrong registration choice is setup, no registraiton performed !!! **** \n");
         return 1;  // :512-514
     }
-    if (regChoice == 1 || regChoice == 3 || regChoice == 4) {
-        // phasor / 2-D MIP pre-registration: "next" rows of the scope table, not built yet.
-        printf("\n ****regChoice %d (phasor / 2D-MIP pre-registration) is not provided by this build **** \n",
-               regChoice);
+    if (regChoice == 1 || regChoice == 3) {
+        // phasor pre-registration: a "next" row of the scope table, not built yet.
+        printf("\n ****regChoice %d (phasor pre-registration) is not provided by this build **** \n", regChoice);
         return -1;
     }
     return guarded("reg3d", [&]() -> int {
@@ -93,6 +92,19 @@ extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, un
         MIL_HIP(hipMemcpyAsync(d_t.get(), h_img1, n1 * sizeof(float), hipMemcpyHostToDevice, sg.s));
         records[9] = free_mb();
         const int method = (regChoice == 0) ? 0 : affMethod;  // :412
+        if (regChoice == 4) {  // 2-D MIP shifts first, then affine from that translation (:448-497)
+            if (verbose) printf("\t... 2D MIP registration ... \n");
+            float shift[3];
+            mip_shift_search(shift, d_t.get(), d_s.get(), d1, sg.s);
+            for (int j = 0; j < 12; ++j) iTmx[j] = 0.f;
+            iTmx[0] = iTmx[5] = iTmx[10] = 1.f;
+            iTmx[3] = shift[0]; iTmx[7] = shift[1]; iTmx[11] = shift[2];
+            if (verbose) {
+                printf("\t... shift translation, X: %2.1f; Y: %2.1f; Z: %2.1f\n", shift[0], shift[1], shift[2]);
+                printf("\t... 2D MIP registration completed. \n\t... 3D registration ... \n");
+            }
+            flagTmx = true;
+        }
         reg3d_affine_device(d_reg.get(), iTmx, d_t.get(), d_s.get(), d1, method, flagTmx, FTOL, itLimit, verbose,
                             records, sg.s);
         MIL_HIP(hipMemcpyAsync(h_reg, d_reg.get(), n1 * sizeof(float), hipMemcpyDeviceToHost, sg.s));

@@ -223,6 +223,25 @@ int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float
     });
 }
 
+int mil_reg3d_mip_shift(float *shift3, const float *d_img1, const float *d_img2, int nx, int ny, int nz, void *stream) {
+    return guarded("mil_reg3d_mip_shift", [&] {
+        hipStream_t s = as_stream(stream);
+        bool own = false;
+        if (!s) {
+            MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            own = true;
+        }
+        try {
+            mip_shift_search(shift3, d_img1, d_img2, dims3(nx, ny, nz), s);
+        } catch (...) {
+            if (own) (void)hipStreamDestroy(s);
+            throw;
+        }
+        if (own) (void)hipStreamDestroy(s);
+        return 0;
+    });
+}
+
 int mil_powell(float *p, float *xi, int ld, int n, float ftol, int *iter, float *fret, mil_cost_fn f, void *user,
                int *totalIt, int itLimit) {
     if (n < 1 || ld < n || !f || !totalIt) return -1;

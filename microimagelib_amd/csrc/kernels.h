@@ -66,10 +66,11 @@ struct CorrWorkspace {
 };
 // Enqueue the fused interpolate + correlate + reduce; result lands in ws.host after
 // the stream is synchronised (corr_sums_sync does that and returns it).
+// float_products: form s*s and s*t in float32 before the float64 sums (the reference's 2-D cost).
 void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
-                     CorrWorkspace &ws, hipStream_t s);
+                     CorrWorkspace &ws, hipStream_t s, bool float_products = false);
 void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
-                    CorrWorkspace &ws, hipStream_t s, double *ss, double *st);
+                    CorrWorkspace &ws, hipStream_t s, double *ss, double *st, bool float_products = false);
 
 }  // namespace k
 }  // namespace mil

@@ -117,6 +117,77 @@ bool check_matrix(const float *m, long long sx, long long sy, long long sz) {
 }
 
 // ---------------------------------------------------------------------------
+// 2-D MIP shift search (regChoice 4)
+// ---------------------------------------------------------------------------
+namespace {
+
+// reg2d_shiftalign1 (x_only = false) / reg2d_shiftalignX1 (x_only = true) on device-resident images of equal size
+// w x h.  aff6 = (a0 a1 tx; a3 a4 ty) in/out.  A 2-D image is handled as a one-plane volume: with a zero z column
+// the 3-D coordinate expression adds exact zeros, so the arithmetic is that of corr2Dkernel.
+void shift_align_2d(float aff6[6], const float *d_img1, const float *d_img2, int w, int h, bool x_only,
+                    k::ReduceWorkspace &red, k::CorrWorkspace &corr, hipStream_t s) {
+    const Dims d{w, h, 1};
+    const size_t n = (size_t)w * h;
+    DeviceBuffer<float> t_ms(n), s_ms(n);
+    const double sum1 = k::reduce_sync(k::kSum, d_img1, n, 0.f, red, s);
+    k::add_value(t_ms.get(), d_img1, -((float)sum1 / (float)n), n, s);
+    const float sd_t = (float)std::sqrt(k::reduce_sync(k::kSumSqShifted, t_ms.get(), n, 0.f, red, s));
+    if (sd_t == 0.f) throw Error(-3, "2-D MIP registration: SD of the target projection is zero (empty image)");
+    const double sum2 = k::reduce_sync(k::kSum, d_img2, n, 0.f, red, s);
+    k::add_value(s_ms.get(), d_img2, -((float)sum2 / (float)n), n, s);
+
+    auto zncc = [&](const float *a) -> float {  // -costfunc2D, src/api_subfunc.cu:1815-1821 + corrfunc2D :1014-1036
+        k::Affine12 m = {{a[0], a[1], 0.f, a[2], a[3], a[4], 0.f, a[5], 0.f, 0.f, 1.f, 0.f}};
+        double ss = 0, st = 0;
+        k::corr_sums_sync(t_ms.get(), s_ms.get(), d, d, m, corr, s, &ss, &st, /*float_products=*/true);
+        if (std::sqrt(ss) == 0) return -2.0f;
+        return (float)(st / std::sqrt(ss)) / sd_t;
+    };
+    const float shift_region = 0.3f, total_step = 30.f;  // src/api_reg.cpp:463-464
+    float p[6];
+    std::memcpy(p, aff6, sizeof p);
+    const float off_x = p[2], off_y = p[5];
+    const float step_x = (float)w * shift_region / total_step, step_y = (float)h * shift_region / total_step;
+    float best = 0.f, best_x = 0.f, best_y = 0.f;
+    for (int i = -(int)total_step; i < (int)total_step; ++i) {
+        p[2] = off_x + step_x * (float)i;
+        if (x_only) {
+            const float c = zncc(p);
+            if (c > best) { best = c; best_x = p[2]; }
+        } else {
+            for (int j = -(int)total_step; j < (int)total_step; ++j) {
+                p[5] = off_y + step_y * (float)j;
+                const float c = zncc(p);
+                if (c > best) { best = c; best_x = p[2]; best_y = p[5]; }
+            }
+        }
+    }
+    p[2] = best_x;
+    if (!x_only) p[5] = best_y;
+    std::memcpy(aff6, p, sizeof p);
+}
+
+}  // namespace
+
+void mip_shift_search(float shift[3], const float *d_img1, const float *d_img2, Dims dims, hipStream_t stream) {
+    const size_t nxy = (size_t)dims.nx * dims.ny, nzx = (size_t)dims.nz * dims.nx;
+    DeviceBuffer<float> p1(nxy > nzx ? nxy : nzx), p2(nxy > nzx ? nxy : nzx);
+    k::ReduceWorkspace red;
+    k::CorrWorkspace corr;
+    k::max_projection(p1.get(), d_img1, dims, 1, stream);  // [ny][nx]
+    k::max_projection(p2.get(), d_img2, dims, 1, stream);
+    float t1[6] = {1, 0, 0, 0, 1, 0};
+    shift_align_2d(t1, p1.get(), p2.get(), (int)dims.nx, (int)dims.ny, false, red, corr, stream);
+    k::max_projection(p1.get(), d_img1, dims, 2, stream);  // width nz, height nx
+    k::max_projection(p2.get(), d_img2, dims, 2, stream);
+    float t2[6] = {1, 0, 0, 0, 1, t1[2]};
+    shift_align_2d(t2, p1.get(), p2.get(), (int)dims.nz, (int)dims.nx, true, red, corr, stream);
+    shift[0] = t1[2];
+    shift[1] = t1[5];
+    shift[2] = t2[2];
+}
+
+// ---------------------------------------------------------------------------
 // driver
 // ---------------------------------------------------------------------------
 namespace {

@@ -28,4 +28,9 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
                         int aff_method, bool flag_tmx, float ftol, int it_limit, bool verbose, float *records,
                         hipStream_t stream, const RegOptions &opt = RegOptions());
 
+// 2-D MIP pre-registration of regChoice 4, reference src/api_reg.cpp:448-497 with reg2d_shiftalign1 /
+// reg2d_shiftalignX1 (src/api_subfunc.cu:1860-2120): exhaustive 60 x 60 search of the XY shift on the z projections,
+// then 60 steps of the z shift on the y projections with the x shift held.  shift = {x, y, z} in voxels.
+void mip_shift_search(float shift[3], const float *d_img1, const float *d_img2, Dims dims, hipStream_t stream);
+
 }  // namespace mil

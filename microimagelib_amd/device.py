@@ -136,6 +136,14 @@ def reg3d_affine(target: torch.Tensor, source: torch.Tensor, aff_method=6, i_tmx
     return reg, tmx, rec
 
 
+def reg3d_mip_shift(target: torch.Tensor, source: torch.Tensor, stream=None):
+    """regChoice 4 pre-registration: (shift_x, shift_y, shift_z) from 2-D MIP grid searches."""
+    shift = np.zeros(3, dtype=np.float32)
+    _check(_lib.load().mil_reg3d_mip_shift(shift.ctypes.data_as(_lib.c_float_p), _ptr(target), _ptr(source),
+                                           *_dims(target), _stream_ptr(stream)), "mil_reg3d_mip_shift")
+    return shift
+
+
 # ---- deconvolution engine ----------------------------------------------------------
 class DeconEngine:
     """RL engine for one FFT box (shape ``(nz, ny, nx)``) on the current device."""

@@ -320,3 +320,92 @@ class Reg3dAffine:
         records[5] = counter[0]
         reg = affine_transform(source, aff, shape)  # raw source  :2974-2977
         return reg, aff, records
+
+
+# ---------------------------------------------------------------- 2-D MIP shift search (regChoice 4)
+def max_projection(vol, direction):
+    """maxprojectionkernel, include/cukernel.cuh:396-418 (+ wrapper src/api_subfunc.cu:490-510): the
+    accumulator starts at 0, so negative data projects to 0.  direction 1: along z -> [sy][sx];
+    direction 2: along y -> image of width sz, height sx ([sx][sz]); direction 3: along x -> [sz][sy]."""
+    vol = np.asarray(vol, dtype=f32)
+    if direction == 1:
+        p = vol.max(axis=0)                 # [y][x]
+    elif direction == 2:
+        p = vol.max(axis=1).T               # [x][z]
+    elif direction == 3:
+        p = vol.max(axis=2)                 # [z][y]
+    else:
+        raise ValueError(direction)
+    return np.maximum(p, f32(0)).astype(f32)
+
+
+def _matrix_2d(a6):
+    """2-D matrix (a0 a1 a2; a3 a4 a5) as the 3-D matrix of a one-plane volume: identical float32
+    arithmetic, since the z terms add exact zeros (include/cukernel.cuh:585-586 vs :539-541)."""
+    a = np.asarray(a6, dtype=f32)
+    return np.array([a[0], a[1], 0, a[2], a[3], a[4], 0, a[5], 0, 0, 1, 0], dtype=f32)
+
+
+def corrfunc2d(target_ms, sd_t, source_ms, a6):
+    """corrfunc2D + corr2Dkernel, src/api_subfunc.cu:1014-1036, include/cukernel.cuh:575-597: the products
+    t*t and s*t are formed in float32 and summed in float64 on the host."""
+    tgt = np.asarray(target_ms, dtype=f32)[None]
+    src = np.asarray(source_ms, dtype=f32)[None]
+    tx, ty, tz = _coords(_matrix_2d(a6), tgt.shape)
+    valid = (tx > 0) & (tx < f32(src.shape[2])) & (ty > 0) & (ty < f32(src.shape[1]))
+    t = np.where(valid, _trilinear(src, tx, ty, tz), f32(0)).astype(f32)
+    sqr = float(np.sum((t * t).astype(f32), dtype=np.float64))
+    cor = float(np.sum((tgt * t).astype(f32), dtype=np.float64))
+    if np.sqrt(sqr) == 0:
+        return f32(-2.0)
+    return f32(f32(cor / np.sqrt(sqr)) / f32(sd_t))
+
+
+def shift_align_2d(img1, img2, tmx6=None, x_only=False, shift_region=0.3, total_step=30):
+    """reg2d_shiftalign1 / reg2d_shiftalignX1, src/api_subfunc.cu:1860-1990, 2000-2120: exhaustive search of
+    the translation on a (2*total_step)^2 (or 2*total_step) grid, best ZNCC wins (strictly greater than 0).
+    Images are [h][w]; returns the 6-vector (a0 a1 tx; a3 a4 ty)."""
+    img1 = np.asarray(img1, dtype=f32)
+    img2 = np.asarray(img2, dtype=f32)
+    h1, w1 = img1.shape
+    h2, w2 = img2.shape
+    if tmx6 is not None:
+        aff = np.asarray(tmx6, dtype=f32).copy()
+    else:
+        aff = np.array([1, 0, (w2 - w1) // 2, 0, 1, (h2 - h1) // 2], dtype=f32)
+    t_ms, _ = mean_subtract(img1)
+    sq = float(np.sum((t_ms * t_ms).astype(f32), dtype=np.float64))
+    sd_t = f32(np.sqrt(sq))
+    if sd_t == 0:
+        raise ValueError("SD of image 1 is zero")
+    s_ms, _ = mean_subtract(img2)
+    p = aff.copy()
+    off_x, off_y = p[2], p[5]
+    best, sx_best, sy_best = f32(0), f32(0), f32(0)
+    step_x = f32(f32(f32(w2) * f32(shift_region)) / f32(total_step))
+    step_y = f32(f32(f32(h2) * f32(shift_region)) / f32(total_step))
+    n = int(total_step)
+    for i in range(-n, n):
+        p[2] = f32(off_x + f32(step_x * f32(i)))
+        js = [None] if x_only else range(-n, n)
+        for j in js:
+            if j is not None:
+                p[5] = f32(off_y + f32(step_y * f32(j)))
+            c = corrfunc2d(t_ms, sd_t, s_ms, p)
+            if c > best:
+                best, sx_best = c, p[2]
+                if j is not None:
+                    sy_best = p[5]
+    p[2] = sx_best
+    if not x_only:
+        p[5] = sy_best
+    return p.astype(f32), f32(corrfunc2d(t_ms, sd_t, s_ms, p))
+
+
+def mip_shift_search(target, source):
+    """regChoice 4 pre-registration, src/api_reg.cpp:462-492: XY shift from the z-projections, then the
+    z shift from the y-projections with the x shift held.  Returns (shift_x, shift_y, shift_z)."""
+    t1, _ = shift_align_2d(max_projection(target, 1), max_projection(source, 1))
+    t2, _ = shift_align_2d(max_projection(target, 2), max_projection(source, 2),
+                           tmx6=np.array([1, 0, 0, 0, 1, t1[2]], dtype=f32), x_only=True)
+    return np.array([t1[2], t1[5], t2[2]], dtype=f32)

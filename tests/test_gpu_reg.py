@@ -164,3 +164,30 @@ def test_mip3d_matches_oracle(api):
             m = ro.rot2matrix(f32(step * f32(i)), sx, sy, sz, axis)
             want = np.maximum(ro.affine_transform(vol, m, box).max(axis=0), f32(0))
             assert np.max(np.abs(got[i] - want)) <= 1e-4 * vol.max(), f"axis {axis} angle {i}"
+
+
+# ---------------------------------------------------------------- regChoice 4: 2-D MIP shift search
+def _shifted_pair(shape=(24, 40, 48), shift=(3.0, -2.0, 1.6)):
+    tgt = do.blob_volume(shape, n_blobs=15, seed=3)
+    m = np.array([1, 0, 0, -shift[0], 0, 1, 0, -shift[1], 0, 0, 1, -shift[2]], dtype=np.float32)
+    return tgt, ro.affine_transform(tgt, m, tgt.shape)
+
+
+def test_mip_shift_search_matches_oracle():
+    import torch
+    from microimagelib_amd import device
+    tgt, src = _shifted_pair()
+    got = device.reg3d_mip_shift(torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda())
+    want = ro.mip_shift_search(tgt, src)
+    assert np.array_equal(got, want), (got, want)  # same grid point on every axis
+    assert np.all(np.abs(got - np.array([3.0, -2.0, 1.6])) < 0.5)  # within one grid step of the true shift
+
+
+def test_reg3d_regchoice4_recovers_shift():
+    """regChoice 4 through libapi.h: MIP shifts seed the affine stage (src/api_reg.cpp:448-497)."""
+    from microimagelib_amd import api
+    tgt, src = _shifted_pair()
+    reg, tmx, rec = api.reg3d(tgt, src, reg_choice=4, aff_method=1, it_limit=300)
+    assert rec[3] > rec[1] and rec[3] > 0.9, rec  # final ZNCC (the shifted copy has zero-filled borders)
+    assert abs(tmx[3] - 3.0) < 0.3 and abs(tmx[7] + 2.0) < 0.3 and abs(tmx[11] - 1.6) < 0.3, tmx
+    assert np.allclose(tmx[[0, 5, 10]], 1.0) and np.allclose(tmx[[1, 2, 4, 6, 8, 9]], 0.0)
