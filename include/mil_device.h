@@ -102,6 +102,14 @@ int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float
  * (src/api_subfunc.cu:1860-2120).  shift3 = {x, y, z} translation in voxels (host). */
 int mil_reg3d_mip_shift(float *shift3, const float *d_img1, const float *d_img2, int nx, int ny, int nz, void *stream);
 
+/* regChoice 1 / 3 pre-registration: reg3d_phasor1, src/api_subfunc.cu:2465-2590.  shift3 = {x, y, z} (host),
+ * source(p) ~ target(p - shift). */
+int mil_reg3d_phasor_shift(long long *shift3, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
+                           void *stream);
+/* circshiftgpu (wrap != 0) / imshiftgpu (zero fill), src/api_subfunc.cu:827-847: out[p] = in[p - d] */
+int mil_shift_volume(float *d_out, const float *d_in, int nx, int ny, int nz, long long dx, long long dy, long long dz,
+                     int wrap, void *stream);
+
 /* ---- host-side pieces of the path (no GPU needed) --------------------------- */
 /* powell(), src/api_powell.c:305-360.  0-based: p[n]; xi row-major with leading dimension ld,
  * column j = direction j.  f is called with a 0-based parameter vector. */

@@ -86,6 +86,10 @@ SIGNATURES = {
     "mil_reg3d_affine": (C.c_int, [C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, C.c_void_p]),
     "mil_reg3d_mip_shift": (C.c_int, [c_float_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mil_reg3d_phasor_shift": (C.c_int, [C.POINTER(C.c_longlong), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p]),
+    "mil_shift_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong,
+                                   C.c_longlong, C.c_int, C.c_void_p]),
     "mil_powell": (C.c_int, [c_float_p, c_float_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), c_float_p,
                              COST_FN, C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "mil_p2matrix": (None, [c_float_p, c_float_p]),

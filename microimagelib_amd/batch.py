@@ -194,8 +194,14 @@ class FusionPipeline:
 
     def reg_fn(self, target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
         """reg3d on device volumes: regChoice 0 (apply / copy), 2 (affine) and 4 (2-D MIP shift search, then
-        affine from that translation: src/api_reg.cpp:448-497); the phasor variants (1, 3) fall back to plain affine."""
+        affine from that translation: src/api_reg.cpp:448-497), 1 / 3 (phasor shift; 3 continues with affine)."""
         method = 0 if reg_choice == 0 else aff_method
+        if reg_choice in (1, 3):
+            sx, sy, sz = (float(v) for v in self._mdev.reg3d_phasor_shift(target, source))
+            i_tmx, input_tmx = np.array([1, 0, 0, sx, 0, 1, 0, sy, 0, 0, 1, sz], dtype=np.float32), True
+            if reg_choice == 1:  # the shifted source is the result (src/api_reg.cpp:418-427)
+                reg = self._mdev.shift_volume(source, -int(sx), -int(sy), -int(sz), wrap=False)
+                return reg, i_tmx, np.zeros(11, dtype=np.float32)
         if reg_choice == 4:
             sx, sy, sz = self._mdev.reg3d_mip_shift(target, source)
             i_tmx, input_tmx = np.array([1, 0, 0, sx, 0, 1, 0, sy, 0, 0, 1, sz], dtype=np.float32), True

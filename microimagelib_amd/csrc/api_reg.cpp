@@ -64,11 +64,7 @@ extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, un
         printf("\n*** Wrong registration choice is setup, no registraiton performed !!! **** \n");
         return 1;  // :512-514
     }
-    if (regChoice == 1 || regChoice == 3) {
-        // phasor pre-registration: a "next" row of the scope table, not built yet.
-        printf("\n ****regChoice %d (phasor pre-registration) is not provided by this build **** \n", regChoice);
-        return -1;
-    }
+
     return guarded("reg3d", [&]() -> int {
         const auto t0 = std::chrono::steady_clock::now();
         MIL_HIP(hipSetDevice(deviceNum));
@@ -92,6 +88,22 @@ extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, un
         MIL_HIP(hipMemcpyAsync(d_t.get(), h_img1, n1 * sizeof(float), hipMemcpyHostToDevice, sg.s));
         records[9] = free_mb();
         const int method = (regChoice == 0) ? 0 : affMethod;  // :412
+        if (regChoice == 1 || regChoice == 3) {  // phasor: pixel-level translation (:418-446)
+            long long sh[3];
+            phasor_shift(sh, d_t.get(), d_s.get(), d1, sg.s);
+            for (int j = 0; j < 12; ++j) iTmx[j] = 0.f;
+            iTmx[0] = iTmx[5] = iTmx[10] = 1.f;
+            iTmx[3] = (float)sh[0]; iTmx[7] = (float)sh[1]; iTmx[11] = (float)sh[2];
+            if (regChoice == 1) {  // the shifted source IS the result
+                k::shift_volume(d_reg.get(), d_s.get(), d1, -sh[0], -sh[1], -sh[2], false, sg.s);
+                MIL_HIP(hipMemcpyAsync(h_reg, d_reg.get(), n1 * sizeof(float), hipMemcpyDeviceToHost, sg.s));
+                MIL_HIP(hipStreamSynchronize(sg.s));
+                records[10] = free_mb();
+                records[7] = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                return 0;
+            }
+            flagTmx = true;  // regChoice 3: affine from that translation
+        }
         if (regChoice == 4) {  // 2-D MIP shifts first, then affine from that translation (:448-497)
             if (verbose) printf("\t... 2D MIP registration ... \n");
             float shift[3];

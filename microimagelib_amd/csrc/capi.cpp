@@ -242,6 +242,33 @@ int mil_reg3d_mip_shift(float *shift3, const float *d_img1, const float *d_img2,
     });
 }
 
+int mil_reg3d_phasor_shift(long long *shift3, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
+                           void *stream) {
+    return guarded("mil_reg3d_phasor_shift", [&] {
+        hipStream_t s = as_stream(stream);
+        bool own = false;
+        if (!s) {
+            MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            own = true;
+        }
+        try {
+            phasor_shift(shift3, d_img1, d_img2, dims3(nx, ny, nz), s);
+        } catch (...) {
+            if (own) (void)hipStreamDestroy(s);
+            throw;
+        }
+        if (own) (void)hipStreamDestroy(s);
+        return 0;
+    });
+}
+int mil_shift_volume(float *d_out, const float *d_in, int nx, int ny, int nz, long long dx, long long dy, long long dz,
+                     int wrap, void *stream) {
+    return guarded("mil_shift_volume", [&] {
+        k::shift_volume(d_out, d_in, dims3(nx, ny, nz), dx, dy, dz, wrap != 0, as_stream(stream));
+        return 0;
+    });
+}
+
 int mil_powell(float *p, float *xi, int ld, int n, float ftol, int *iter, float *fret, mil_cost_fn f, void *user,
                int *totalIt, int itLimit) {
     if (n < 1 || ld < n || !f || !totalIt) return -1;

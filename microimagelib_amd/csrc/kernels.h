@@ -49,6 +49,28 @@ void rot_y90(float *out, const float *in, Dims in_dims, int direction, hipStream
 // maximum-intensity projections with accumulator starting at 0 (maxprojectionkernel).
 void max_projection(float *out, const float *in, Dims d, int direction, hipStream_t s);
 
+// out[p] = in[p - d]: circular (circshiftgpu) or zero-filled (imshiftgpu), reference include/cukernel.cuh:457-489.
+void shift_volume(float *out, const float *in, Dims d, long long dx, long long dy, long long dz, bool wrap, hipStream_t s);
+// crop of extent S at offset (ox, oy, oz) of a volume F (cropgpu2, reference src/api_subfunc.cu:1759).
+void crop_offset(float *out, const float *in, Dims S, Dims F, long long ox, long long oy, long long oz, hipStream_t s);
+// out = conj(s1) * s2 / |conj(s1) * s2| (0 where the product vanishes): conj3Dgpu + multicomplexnorm3Dgpu.
+void cross_power_norm(float2 *out, const float2 *s1, const float2 *s2, size_t n, hipStream_t s);
+// per (x, y) column: first maximum along z and its index (maxZkernel).
+void argmax_columns(float *col_max, int *col_arg, const float *in, Dims d, hipStream_t s);
+// sum over i of float32((a[i]+ca) * (b[i]+cb)), accumulated in float64.  Synchronises `s`.
+double reduce_dot_sync(const float *a, const float *b, size_t n, float ca, float cb, ReduceWorkspace &ws, hipStream_t s);
+
+// out[p] = in[p - d]: circular (circshiftgpu) or zero-filled (imshiftgpu), reference include/cukernel.cuh:457-489.
+void shift_volume(float *out, const float *in, Dims d, long long dx, long long dy, long long dz, bool wrap, hipStream_t s);
+// crop of extent S at offset (ox, oy, oz) of a volume F (cropgpu2, reference src/api_subfunc.cu:1759).
+void crop_offset(float *out, const float *in, Dims S, Dims F, long long ox, long long oy, long long oz, hipStream_t s);
+// out = conj(s1) * s2 / |conj(s1) * s2| (0 where the product vanishes): conj3Dgpu + multicomplexnorm3Dgpu.
+void cross_power_norm(float2 *out, const float2 *s1, const float2 *s2, size_t n, hipStream_t s);
+// per (x, y) column: first maximum along z and its index (maxZkernel).
+void argmax_columns(float *col_max, int *col_arg, const float *in, Dims d, hipStream_t s);
+// sum over i of float32((a[i]+ca) * (b[i]+cb)), accumulated in float64.  Synchronises `s`.
+double reduce_dot_sync(const float *a, const float *b, size_t n, float ca, float cb, ReduceWorkspace &ws, hipStream_t s);
+
 // ---- affine (affine.hip) ---------------------------------------------------
 struct Affine12 {
     float m[12];

@@ -370,6 +370,70 @@ __global__ void max_projection_kernel(float *__restrict__ out, const float *__re
     out[i + (size_t)j * psx] = a;
 }
 
+// circshiftgpukernel / imshiftgpukernel, reference include/cukernel.cuh:457-489: out[p] = in[p - d], circular
+// (wrap != 0) or zero-filled.  g.o* carry the shift, g.f* = g.s* = the volume.
+__global__ void shift_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g, int wrap) {
+    int x, y, z;
+    if (!out_xyz(g, x, y, z)) return;
+    int tx = x - g.ox, ty = y - g.oy, tz = z - g.oz;
+    float v = 0.0f;
+    if (wrap) {
+        tx = ((tx % g.fx) + g.fx) % g.fx;
+        ty = ((ty % g.fy) + g.fy) % g.fy;
+        tz = ((tz % g.fz) + g.fz) % g.fz;
+        v = in[(size_t)tx + (size_t)g.fx * ((size_t)ty + (size_t)g.fy * tz)];
+    } else if (tx >= 0 && tx < g.fx && ty >= 0 && ty < g.fy && tz >= 0 && tz < g.fz) {
+        v = in[(size_t)tx + (size_t)g.fx * ((size_t)ty + (size_t)g.fy * tz)];
+    }
+    out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] = v;
+}
+
+// multicomplexnorm3Dkernel with conj3Dkernel folded in, reference include/cukernel.cuh:155-177, 209-219:
+// out = conj(s1) * s2 / |conj(s1) * s2|, zero where the product vanishes.
+__global__ __launch_bounds__(kBlock) void cross_power_kernel(float2 *__restrict__ out, const float2 *__restrict__ s1,
+                                                           const float2 *__restrict__ s2, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const float2 a = make_float2(s1[i].x, -s1[i].y), b = s2[i];
+        const float c = a.x * b.x - a.y * b.y;
+        const float d = a.x * b.y + a.y * b.x;
+        const float e = sqrtf(c * c + d * d);
+        out[i] = (e != 0.0f) ? make_float2(c / e, d / e) : make_float2(0.0f, 0.0f);
+    }
+}
+
+// maxZkernel, reference include/cukernel.cuh:364-380: per (x, y) column the first maximum along z (strict <).
+__global__ void argmax_z_kernel(float *__restrict__ col_max, int *__restrict__ col_arg, const float *__restrict__ in,
+                                int sx, int sy, int sz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= sx || j >= sy) return;
+    const size_t zs = (size_t)sx * sy, base = (size_t)i + (size_t)sx * j;
+    float p = in[base];
+    int z0 = 0;
+    for (int k = 0; k < sz; ++k) {
+        const float v = in[base + zs * k];
+        if (p < v) {
+            p = v;
+            z0 = k;
+        }
+    }
+    col_max[base] = p;
+    col_arg[base] = z0;
+}
+
+// sum of float32 products (a+ca)*(b+cb) in float64: the reference's addvaluegpu + multi3Dgpu + sum3Dgpu chain of zncc1
+__global__ __launch_bounds__(kBlock) void reduce_dot_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                          size_t n, float ca, float cb, double *__restrict__ partials) {
+    __shared__ double lds[kBlock / 64];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const float u = a[i] + ca, v = b[i] + cb;
+        const float q = u * v;
+        acc += (double)q;
+    }
+    const double r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 inline void geo_launch_dims(const Geo &g, dim3 &grid, dim3 &block) {
     int bx = g.fx >= 256 ? 256 : (g.fx > 64 ? 128 : 64);
     block = dim3(bx, 1, 1);
@@ -534,6 +598,54 @@ void max_projection(float *out, const float *in, Dims d, int direction, hipStrea
     hipLaunchKernelGGL(max_projection_kernel, dim3((psx + bx - 1) / bx, psy, 1), dim3(bx), 0, s, out, in, sx, sy, sz,
                        psx, psy, psz, direction);
     MIL_HIP(hipGetLastError());
+}
+
+void shift_volume(float *out, const float *in, Dims d, long long dx, long long dy, long long dz, bool wrap,
+                  hipStream_t s) {
+    Geo g = make_geo(d, d);
+    g.ox = (int)dx; g.oy = (int)dy; g.oz = (int)dz;
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(shift_kernel, grid, block, 0, s, out, in, g, wrap ? 1 : 0);
+    MIL_HIP(hipGetLastError());
+}
+
+void crop_offset(float *out, const float *in, Dims S, Dims F, long long ox, long long oy, long long oz, hipStream_t s) {
+    if (ox < 0 || oy < 0 || oz < 0 || ox + S.nx > F.nx || oy + S.ny > F.ny || oz + S.nz > F.nz)
+        throw Error(-1, "crop_offset: crop outside the volume");
+    Geo g = make_geo(S, F);
+    g.ox = (int)ox; g.oy = (int)oy; g.oz = (int)oz;
+    dim3 grid, block;
+    geo_launch_dims(g, grid, block);
+    hipLaunchKernelGGL(crop_kernel, grid, block, 0, s, out, in, g);
+    MIL_HIP(hipGetLastError());
+}
+
+void cross_power_norm(float2 *out, const float2 *s1, const float2 *s2, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(cross_power_kernel, dim3(flat_grid(n)), dim3(kBlock), 0, s, out, s1, s2, n);
+    MIL_HIP(hipGetLastError());
+}
+
+void argmax_columns(float *col_max, int *col_arg, const float *in, Dims d, hipStream_t s) {
+    const int bx = d.nx >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(argmax_z_kernel, dim3((unsigned)((d.nx + bx - 1) / bx), (unsigned)d.ny, 1), dim3(bx), 0, s, col_max,
+                       col_arg, in, (int)d.nx, (int)d.ny, (int)d.nz);
+    MIL_HIP(hipGetLastError());
+}
+
+double reduce_dot_sync(const float *a, const float *b, size_t n, float ca, float cb, ReduceWorkspace &ws, hipStream_t s) {
+    if (n == 0) return 0.0;
+    size_t want = (n + kBlock - 1) / kBlock;
+    const int blocks = (int)(want > (size_t)kMaxReduceBlocks ? kMaxReduceBlocks : want);
+    double *out = ws.partials.get() + 2 * kMaxReduceBlocks;
+    hipLaunchKernelGGL(reduce_dot_kernel, dim3(blocks), dim3(kBlock), 0, s, a, b, n, ca, cb, ws.partials.get());
+    MIL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws.partials.get(), blocks, 1, out);
+    MIL_HIP(hipGetLastError());
+    MIL_HIP(hipMemcpyAsync(ws.host, out, sizeof(double), hipMemcpyDeviceToHost, s));
+    MIL_HIP(hipStreamSynchronize(s));
+    return ws.host[0];
 }
 
 }  // namespace k

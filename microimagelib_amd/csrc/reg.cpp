@@ -4,6 +4,9 @@
 #include <cmath>
 #include <cstring>
 
+#include <vector>
+
+#include "decon.h"
 #include "powell.h"
 
 namespace mil {
@@ -185,6 +188,102 @@ void mip_shift_search(float shift[3], const float *d_img1, const float *d_img2, 
     shift[0] = t1[2];
     shift[1] = t1[5];
     shift[2] = t2[2];
+}
+
+// ---------------------------------------------------------------------------
+// 3-D phasor shift (regChoice 1 / 3)
+// ---------------------------------------------------------------------------
+namespace {
+
+// zncc1, reference src/api_subfunc.cu:2409-2432
+float zncc_volumes(const float *a, const float *b, size_t n, k::ReduceWorkspace &red, hipStream_t s) {
+    const double sa = k::reduce_sync(k::kSum, a, n, 0.f, red, s), sb = k::reduce_sync(k::kSum, b, n, 0.f, red, s);
+    const float ca = -(float)sa / (float)n, cb = -(float)sb / (float)n;
+    const double st = k::reduce_dot_sync(a, b, n, ca, cb, red, s);
+    const double tt = k::reduce_dot_sync(a, a, n, ca, ca, red, s);
+    const double ss = k::reduce_dot_sync(b, b, n, cb, cb, red, s);
+    const float den = (float)std::sqrt(tt * ss);
+    return den != 0.f ? (float)(st / den) : -2.0f;
+}
+
+}  // namespace
+
+void phasor_shift(long long shift[3], const float *d_img1, const float *d_img2, Dims dims, hipStream_t stream) {
+    const long long sx = dims.nx, sy = dims.ny, sz = dims.nz;
+    const size_t n = (size_t)dims.count(), ns = (size_t)(sx / 2 + 1) * sy * sz;
+    k::ReduceWorkspace red;
+    {
+        Fft3D fft(dims, stream);
+        DeviceBuffer<float2> spec1(ns), spec2(ns);
+        DeviceBuffer<float> work(n), phasor(n), shifted(n);
+        // rocFFT real transforms may overwrite their input: transform copies (:2475-2484)
+        MIL_HIP(hipMemcpyAsync(work.get(), d_img1, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        fft.r2c(work.get(), spec1.get());
+        MIL_HIP(hipMemcpyAsync(work.get(), d_img2, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        fft.r2c(work.get(), spec2.get());
+        k::cross_power_norm(spec2.get(), spec1.get(), spec2.get(), ns, stream);
+        fft.c2r(spec2.get(), phasor.get());
+        k::shift_volume(shifted.get(), phasor.get(), dims, sx / 2, sy / 2, sz / 2, true, stream);  // :2487
+        // max3Dgpu :437-471: column maxima on the device, columns scanned x-outer / y-inner on the host
+        DeviceBuffer<float> col_max((size_t)sx * sy);
+        DeviceBuffer<int> col_arg((size_t)sx * sy);
+        k::argmax_columns(col_max.get(), col_arg.get(), shifted.get(), dims, stream);
+        std::vector<float> h_max((size_t)sx * sy);
+        std::vector<int> h_arg((size_t)sx * sy);
+        MIL_HIP(hipMemcpyAsync(h_max.data(), col_max.get(), h_max.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        MIL_HIP(hipMemcpyAsync(h_arg.data(), col_arg.get(), h_arg.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+        MIL_HIP(hipStreamSynchronize(stream));
+        float peak = h_max[0];
+        long long px = 0, py = 0, pz = 0;  // like the reference: (0,0,0) with the value of column 0 until something is larger
+        for (long long i = 0; i < sx; ++i)
+            for (long long j = 0; j < sy; ++j) {
+                const float t = h_max[(size_t)(i + j * sx)];
+                if (peak < t) {
+                    peak = t;
+                    px = i;
+                    py = j;
+                    pz = h_arg[(size_t)(i + j * sx)];
+                }
+            }
+        shift[0] = px - sx / 2;
+        shift[1] = py - sy / 2;
+        shift[2] = pz - sz / 2;
+    }
+    // wrap-around disambiguation, only for shifts beyond a quarter of the extent (:2497-2588)
+    const long long beta = 4, d[3] = {sx, sy, sz};
+    long long ab[3];
+    for (int a = 0; a < 3; ++a) ab[a] = shift[a] < 0 ? -shift[a] : shift[a];
+    if (!(ab[0] > sx / beta || ab[1] > sy / beta || ab[2] > sz / beta)) return;
+    DeviceBuffer<float> moved(n), crop1(n), crop2(n);
+    k::shift_volume(moved.get(), d_img2, dims, -shift[0], -shift[1], -shift[2], true, stream);
+    long long size[3][2], org[3][2];
+    for (int a = 0; a < 3; ++a) {
+        size[a][0] = d[a] - ab[a];
+        size[a][1] = ab[a];
+        if (shift[a] > 0) { org[a][0] = 0; org[a][1] = d[a] - ab[a]; }
+        else { org[a][0] = ab[a]; org[a][1] = 0; }
+    }
+    float best = -3.f;
+    int ind[3] = {0, 0, 0};
+    for (int i = 0; i < 2; ++i) {
+        if (!(size[0][i] > sx / beta)) continue;
+        for (int j = 0; j < 2; ++j) {
+            if (!(size[1][j] > sy / beta)) continue;
+            for (int kk = 0; kk < 2; ++kk) {
+                if (!(size[2][kk] > sz / beta)) continue;
+                const Dims c{size[0][i], size[1][j], size[2][kk]};
+                k::crop_offset(crop1.get(), d_img1, c, dims, org[0][i], org[1][j], org[2][kk], stream);
+                k::crop_offset(crop2.get(), moved.get(), c, dims, org[0][i], org[1][j], org[2][kk], stream);
+                const float cc = zncc_volumes(crop1.get(), crop2.get(), (size_t)c.count(), red, stream);
+                if (best < cc) {
+                    best = cc;
+                    ind[0] = i; ind[1] = j; ind[2] = kk;
+                }
+            }
+        }
+    }
+    for (int a = 0; a < 3; ++a)
+        if (ind[a] == 1) shift[a] = shift[a] > 0 ? shift[a] - d[a] : shift[a] + d[a];
 }
 
 // ---------------------------------------------------------------------------

@@ -33,4 +33,9 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
 // then 60 steps of the z shift on the y projections with the x shift held.  shift = {x, y, z} in voxels.
 void mip_shift_search(float shift[3], const float *d_img1, const float *d_img2, Dims dims, hipStream_t stream);
 
+// 3-D phasor pre-registration of regChoice 1 / 3, reference reg3d_phasor1 (src/api_subfunc.cu:2465-2590): peak of the
+// inverse transform of the normalised cross-power spectrum, with the reference's wrap-around disambiguation by the
+// ZNCC of the overlapping crops.  shift = {x, y, z}: source(p) ~ target(p - shift).
+void phasor_shift(long long shift[3], const float *d_img1, const float *d_img2, Dims dims, hipStream_t stream);
+
 }  // namespace mil

@@ -144,6 +144,21 @@ def reg3d_mip_shift(target: torch.Tensor, source: torch.Tensor, stream=None):
     return shift
 
 
+def reg3d_phasor_shift(target: torch.Tensor, source: torch.Tensor, stream=None):
+    """regChoice 1 / 3 pre-registration: integer (shift_x, shift_y, shift_z), source(p) ~ target(p - shift)."""
+    shift = (C.c_longlong * 3)()
+    _check(_lib.load().mil_reg3d_phasor_shift(shift, _ptr(target), _ptr(source), *_dims(target), _stream_ptr(stream)),
+           "mil_reg3d_phasor_shift")
+    return np.array([shift[0], shift[1], shift[2]], dtype=np.int64)
+
+
+def shift_volume(a: torch.Tensor, dx: int, dy: int, dz: int, wrap=False, stream=None):
+    out = torch.empty_like(a)
+    _check(_lib.load().mil_shift_volume(_ptr(out), _ptr(a), *_dims(a), int(dx), int(dy), int(dz), int(wrap),
+                                        _stream_ptr(stream)), "mil_shift_volume")
+    return out
+
+
 # ---- deconvolution engine ----------------------------------------------------------
 class DeconEngine:
     """RL engine for one FFT box (shape ``(nz, ny, nx)``) on the current device."""

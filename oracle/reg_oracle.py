@@ -409,3 +409,84 @@ def mip_shift_search(target, source):
     t2, _ = shift_align_2d(max_projection(target, 2), max_projection(source, 2),
                            tmx6=np.array([1, 0, 0, 0, 1, t1[2]], dtype=f32), x_only=True)
     return np.array([t1[2], t1[5], t2[2]], dtype=f32)
+
+
+# ---------------------------------------------------------------- 3-D phasor registration (regChoice 1 / 3)
+def zncc1(a, b):
+    """zncc1, src/api_subfunc.cu:2409-2432: means removed with float(sum)/float(N), products formed in float32
+    (multi3Dgpu), sums in float64; -2 when a variance vanishes."""
+    a, _ = mean_subtract(a)
+    b, _ = mean_subtract(b)
+    st = float(np.sum((a * b).astype(f32), dtype=np.float64))
+    tt = float(np.sum((a * a).astype(f32), dtype=np.float64))
+    ss = float(np.sum((b * b).astype(f32), dtype=np.float64))
+    den = f32(np.sqrt(tt * ss))
+    return f32(st / den) if den != 0 else f32(-2.0)
+
+
+def circshift(a, dx, dy, dz):
+    """circshiftgpukernel, include/cukernel.cuh:457-473: out[z][y][x] = in[z-dz][y-dy][x-dx] (circular)."""
+    return np.roll(a, shift=(dz, dy, dx), axis=(0, 1, 2))
+
+
+def imshift(a, dx, dy, dz):
+    """imshiftgpukernel, include/cukernel.cuh:476-489: as circshift but zero-filled."""
+    out = np.zeros_like(a)
+    sz, sy, sx = a.shape
+
+    def rng(d, n):  # destination slice, source slice
+        lo, hi = max(d, 0), min(n + d, n)
+        return slice(lo, hi), slice(lo - d, hi - d)
+    (zd, zs), (yd, ys), (xd, xs) = rng(dz, sz), rng(dy, sy), rng(dx, sx)
+    if zd.start < zd.stop and yd.start < yd.stop and xd.start < xd.stop:
+        out[zd, yd, xd] = a[zs, ys, xs]
+    return out
+
+
+def reg3d_phasor(target, source):
+    """reg3d_phasor1, src/api_subfunc.cu:2465-2590: peak of the inverse transform of the normalised cross-power
+    spectrum conj(F(target)) * F(source) / |.|, centred by a half-size circular shift; when a shift exceeds a
+    quarter of the extent, each axis' wrap-around alternative is judged by the ZNCC of the overlapping crops.
+    Returns integer (shift_x, shift_y, shift_z)."""
+    t = np.asarray(target, dtype=f32)
+    s = np.asarray(source, dtype=f32)
+    sz, sy, sx = t.shape
+    a = np.conj(np.fft.rfftn(t.astype(np.float64)))
+    b = np.fft.rfftn(s.astype(np.float64))
+    c = a * b
+    mag = np.abs(c)
+    c = np.where(mag != 0, c / np.where(mag != 0, mag, 1), 0)
+    ph = np.fft.irfftn(c, s=t.shape, axes=(0, 1, 2))
+    ph = circshift(ph, sx // 2, sy // 2, sz // 2)
+    # max3Dgpu :437-471: first maximum along z per column, then columns scanned x-outer / y-inner, strict <
+    col_arg = np.argmax(ph, axis=0)                      # first occurrence along z
+    col_max = np.take_along_axis(ph, col_arg[None], 0)[0]  # [y][x]
+    order = col_max.T.reshape(-1)                         # x outer, y inner
+    k = int(np.argmax(order))
+    cx, cy = k // sy, k % sy
+    cz = int(col_arg[cy, cx])
+    shift = [cx - sx // 2, cy - sy // 2, cz - sz // 2]
+    ab = [abs(v) for v in shift]
+    beta = 4
+    if ab[0] > sx // beta or ab[1] > sy // beta or ab[2] > sz // beta:
+        moved = circshift(s, -shift[0], -shift[1], -shift[2])
+        dims = (sx, sy, sz)
+        size = [[dims[d] - ab[d], ab[d]] for d in range(3)]
+        org = [([0, dims[d] - ab[d]] if shift[d] > 0 else [ab[d], 0]) for d in range(3)]
+        best, ind = f32(-3), [0, 0, 0]
+        for i in range(2):
+            if size[0][i] > sx // beta:
+                for j in range(2):
+                    if size[1][j] > sy // beta:
+                        for kk in range(2):
+                            if size[2][kk] > sz // beta:
+                                sl = (slice(org[2][kk], org[2][kk] + size[2][kk]),
+                                      slice(org[1][j], org[1][j] + size[1][j]),
+                                      slice(org[0][i], org[0][i] + size[0][i]))
+                                cc = zncc1(t[sl], moved[sl])
+                                if best < cc:
+                                    best, ind = cc, [i, j, kk]
+        for d in range(3):
+            if ind[d] == 1:
+                shift[d] = shift[d] - dims[d] if shift[d] > 0 else shift[d] + dims[d]
+    return np.array(shift, dtype=np.int64)

@@ -191,3 +191,45 @@ def test_reg3d_regchoice4_recovers_shift():
     assert rec[3] > rec[1] and rec[3] > 0.9, rec  # final ZNCC (the shifted copy has zero-filled borders)
     assert abs(tmx[3] - 3.0) < 0.3 and abs(tmx[7] + 2.0) < 0.3 and abs(tmx[11] - 1.6) < 0.3, tmx
     assert np.allclose(tmx[[0, 5, 10]], 1.0) and np.allclose(tmx[[1, 2, 4, 6, 8, 9]], 0.0)
+
+
+# ---------------------------------------------------------------- regChoice 1 / 3: phasor registration
+@pytest.mark.parametrize("shift", [(3, -2, 1), (20, -15, 9), (-30, 4, -8), (0, 0, 0)])
+@pytest.mark.parametrize("wrap", [True, False])
+def test_phasor_shift_matches_oracle(shift, wrap):
+    import torch
+    from microimagelib_amd import device
+    tgt = do.blob_volume((24, 40, 48), n_blobs=15, seed=3, background=0.0)
+    src = ro.circshift(tgt, *shift) if wrap else ro.imshift(tgt, *shift)
+    got = device.reg3d_phasor_shift(torch.from_numpy(tgt).cuda(), torch.from_numpy(np.ascontiguousarray(src)).cuda())
+    want = ro.reg3d_phasor(tgt, src)
+    assert np.array_equal(got, want), (got, want)
+    if wrap and max(abs(shift[0]) * 4 // 48, abs(shift[1]) * 4 // 40, abs(shift[2]) * 4 // 24) == 0:
+        assert tuple(got) == shift  # small circular shifts are recovered exactly
+
+
+def test_shift_volume_matches_oracle():
+    import torch
+    from microimagelib_amd import device
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 1, (7, 9, 20)).astype(np.float32)
+    for d in ((3, -2, 1), (-19, 8, 6), (0, 0, 0), (25, 0, -9)):
+        for wrap in (True, False):
+            got = device.shift_volume(torch.from_numpy(a).cuda(), *d, wrap=wrap).cpu().numpy()
+            want = ro.circshift(a, *d) if wrap else ro.imshift(a, *d)
+            assert np.array_equal(got, want), (d, wrap)
+
+
+def test_reg3d_regchoice1_and_3():
+    """regChoice 1: result = source shifted back, matrix = pure translation (src/api_reg.cpp:418-427);
+    regChoice 3: that translation seeds the affine stage (:434-446)."""
+    from microimagelib_amd import api
+    tgt = do.blob_volume((24, 40, 48), n_blobs=15, seed=3, background=0.0)
+    src = np.ascontiguousarray(ro.circshift(tgt, 5, -3, 2))
+    reg, tmx, _ = api.reg3d(tgt, src, reg_choice=1)
+    assert np.array_equal(tmx, np.array([1, 0, 0, 5, 0, 1, 0, -3, 0, 0, 1, 2], dtype=np.float32))
+    assert np.array_equal(reg, ro.imshift(src, -5, 3, -2))
+    reg3, tmx3, rec3 = api.reg3d(tgt, src, reg_choice=3, aff_method=1, it_limit=200)
+    # the matrix is that of Powell's LAST line-search trial (reference quirk), within Brent's tolerance of the optimum
+    assert abs(tmx3[3] - 5) < 0.5 and abs(tmx3[7] + 3) < 0.5 and abs(tmx3[11] - 2) < 0.5, tmx3
+    assert rec3[3] > 0.9, rec3
