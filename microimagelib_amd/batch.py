@@ -131,7 +131,8 @@ def register_pair(policy: RegPolicy, reg_fn: RegFn, check_fn: CheckFn, target, s
         reg, tmx, rec = attempt(2, p.weighted, True)
         if bad(tmx, rec):
             reg, tmx, rec = attempt(0, p.previous, True)
-        p.weighted = (0.8 * p.weighted + 0.2 * np.asarray(tmx, dtype=np.float32)).astype(np.float32)
+        # double arithmetic, stored as float (src/spim_fusion_batch.cpp:805-807)
+        p.weighted = (0.8 * p.weighted.astype(np.float64) + 0.2 * np.asarray(tmx, dtype=np.float64)).astype(np.float32)
         p.previous = np.array(tmx, dtype=np.float32)
         return reg, tmx, rec
     raise ValueError(f"regMode {p.reg_mode} is not one of 0, 1, 2, 3")

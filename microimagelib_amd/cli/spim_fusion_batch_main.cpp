@@ -1,0 +1,306 @@
+// spimFusionBatch -- dual-view fusion of a time-lapse: for every time point resample / rotate, register view B
+// onto view A according to the registration mode, joint Richardson-Lucy deconvolution, projections.
+// Same 34 (or 36) positional arguments, folder layout, matrix files and log as the reference tool
+// (src/spim_fusion_batch.cpp:58-113, 135-190, 262-296, 613-966) -- "set same with the ImageJ diSPIMFusion plugin".
+// One process, one GPU, like the reference; the multi-GPU driver that shards time points is microimagelib_amd/batch.py.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+
+#include "cli_common.h"
+
+namespace {
+
+void usage(bool full) {
+    printf("\nspimFusionBatch: Dual-view fusion (registration and joint deconvolution) for diSPIM images in batch mode\n");
+    printf("\nUsage:\tspimFusionBatch [34 or 36 mandatory arguments]\n");
+    if (!full) {
+        printf("\nUse command for more details:\n\tspimFusionBatch -help or spimFusionBatch -h\n");
+        return;
+    }
+    static const char *lines[] = {
+        " 1: <path>      Output directory",
+        " 2: <path>      Input image 1 (SPIM A) directory",
+        " 3: <path>      Input image 2 (SPIM B) directory",
+        " 4: <string>    Input image 1 base name",
+        " 5: <string>    Input image 2 base name",
+        " 6: <int>       Input image index - start",
+        " 7: <int>       Input image index - end",
+        " 8: <int>       Input image index - interval",
+        " 9: <int>       Input image index - test (used when argument 16 is 1)",
+        "10-12: <float>  Pixel size X, Y, Z of image 1 (um)",
+        "13-15: <float>  Pixel size X, Y, Z of image 2 (um)",
+        "16: <int>       Registration mode: 0 apply input matrix | 1 register the test image, apply to all |",
+        "                2 dependently, from the previous results | 3 independently",
+        "17: <int>       Image 2 rotation: 0 none | 1: 90 deg by Y-axis | -1: -90 deg by Y-axis",
+        "18: <int>       Initial matrix: 0 identity | 1 input matrix file | 2 3D phase translation | 3 2D max projections",
+        "19: <filename>  Input matrix file (any string unless argument 18 is 1)",
+        "20: <float>     Registration tolerance",
+        "21: <int>       Maximum iteration number for registration",
+        "22, 23: <int>   Save registered image 1 / 2 (0 | 1)",
+        "24, 25: <file>  PSF1 / PSF2 (forward projectors)",
+        "26: <int>       Iteration number for deconvolution",
+        "27-29: <int>    Save max projection of the decon image: X, Y, Z projection (0 | 1)",
+        "30, 31: <int>   Save 3D max projection: X-axis, Y-axis (0 | 1)",
+        "32: <int>       Bit of output images (16 or 32)",
+        "33: <int>       Query GPU information before processing (0 | 1)",
+        "34: <int>       GPU device",
+        "35, 36: <file>  (optional) backward projectors 1 / 2 [flip of the PSFs]",
+    };
+    printf("\tOnly 16-bit or 32-bit standard TIFF images are currently supported.\n\n");
+    for (const char *l : lines) printf("\t%s\n", l);
+    printf("\nArguments are set same with the ImageJ diSPIMFusion plugin.\n");
+}
+
+unsigned int scaled(unsigned int n, float num, float den) { return (unsigned int)std::lround((float)n * num / den); }
+
+struct Log {
+    std::string path;
+    void operator()(const char *fmt, ...) const __attribute__((format(printf, 2, 3))) {
+        va_list ap, ap2;
+        va_start(ap, fmt);
+        va_copy(ap2, ap);
+        vprintf(fmt, ap);
+        va_end(ap);
+        if (FILE *f = fopen(path.c_str(), "a")) {
+            vfprintf(f, fmt, ap2);
+            fclose(f);
+        }
+        va_end(ap2);
+    }
+};
+
+void write_tmx(const std::string &path, const float *m) {
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return;
+    for (int r = 0; r < 3; ++r) fprintf(f, "%f\t%f\t%f\t%f\t\n", m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]);
+    fprintf(f, "%f\t%f\t%f\t%f\n", 0.0, 0.0, 0.0, 1.0);
+    fclose(f);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc == 1) { usage(false); return EXIT_SUCCESS; }
+    if (argc == 2) { usage(!strcmp(argv[1], "-h") || !strcmp(argv[1], "-help")); return EXIT_SUCCESS; }
+    if (argc != 35 && argc != 37) {
+        printf("Arguments do NOT match! Please input exactly 34 or 36 arguments...\nFor more information, use option -help or -h.\n");
+        return 0;
+    }
+    const std::string out_dir = argv[1], dir1 = argv[2], dir2 = argv[3], base1 = argv[4], base2 = argv[5];
+    const int n_start = atoi(argv[6]), n_end = atoi(argv[7]), n_step = atoi(argv[8]) > 0 ? atoi(argv[8]) : 1, n_test = atoi(argv[9]);
+    const float px1[3] = {(float)atof(argv[10]), (float)atof(argv[11]), (float)atof(argv[12])};
+    const float px2[3] = {(float)atof(argv[13]), (float)atof(argv[14]), (float)atof(argv[15])};
+    int reg_mode = atoi(argv[16]);
+    const int rotation = atoi(argv[17]), initial = atoi(argv[18]);
+    const std::string itmx_path = argv[19];
+    const float ftol = (float)atof(argv[20]);
+    const int it_limit = atoi(argv[21]);
+    const bool save_reg1 = atoi(argv[22]) != 0, save_reg2 = atoi(argv[23]) != 0;
+    const std::string psf1_path = argv[24], psf2_path = argv[25];
+    const int iters = atoi(argv[26]);
+    const bool save_xproj = atoi(argv[27]) != 0, save_yproj = atoi(argv[28]) != 0, save_zproj = atoi(argv[29]) != 0;
+    const bool save_3dx = atoi(argv[30]) != 0, save_3dy = atoi(argv[31]) != 0;
+    const unsigned short out_bits = (unsigned short)atoi(argv[32]);
+    const bool query = atoi(argv[33]) != 0;
+    const int device = atoi(argv[34]);
+    const bool unmatch = argc == 37;
+    if (query) queryDevice();
+
+    // ---- output folders (src/spim_fusion_batch.cpp:262-296); directory arguments end with '/'
+    const std::string decon_dir = out_dir + "Decon/", tmx_dir = out_dir + "TMX/", reg1_dir = out_dir + "RegA/",
+                      reg2_dir = out_dir + "RegB/", mp_xy = decon_dir + "MP_ZProj/", mp_yz = decon_dir + "MP_XProj/",
+                      mp_zx = decon_dir + "MP_YProj/", mp_3dx = decon_dir + "MP_3D_Xaxis/", mp_3dy = decon_dir + "MP_3D_Yaxis/";
+    mkdir(out_dir.c_str(), 0755);
+    mkdir(decon_dir.c_str(), 0755);
+    mkdir(tmx_dir.c_str(), 0755);
+    if (save_reg1) mkdir(reg1_dir.c_str(), 0755);
+    if (save_reg2) mkdir(reg2_dir.c_str(), 0755);
+    if (save_zproj) mkdir(mp_xy.c_str(), 0755);
+    if (save_xproj) mkdir(mp_yz.c_str(), 0755);
+    if (save_yproj) mkdir(mp_zx.c_str(), 0755);
+    if (save_3dx) mkdir(mp_3dx.c_str(), 0755);
+    if (save_3dy) mkdir(mp_3dy.c_str(), 0755);
+    Log log{out_dir + "ProcessingLog.txt"};
+
+    // ---- geometry from the first time point (:400-452)
+    auto name_of = [](const std::string &dir, const std::string &base, int n) { return dir + base + std::to_string(n) + ".tif"; };
+    const int n_probe = reg_mode == 1 ? n_test : n_start;
+    unsigned int in1[3], in2[3];
+    const unsigned int in_bits = gettifinfo(const_cast<char *>(name_of(dir1, base1, n_probe).c_str()), in1);
+    (void)gettifinfo(const_cast<char *>(name_of(dir2, base2, n_probe).c_str()), in2);
+    unsigned int size[3] = {in1[0], scaled(in1[1], px1[1], px1[0]), scaled(in1[2], px1[2], px1[0])};
+    unsigned int sc2[3] = {scaled(in2[0], px2[0], px1[0]), scaled(in2[1], px2[1], px1[0]), scaled(in2[2], px2[2], px1[0])};
+    unsigned int size2[3] = {sc2[0], sc2[1], sc2[2]};
+    int op_choice = 0;
+    if (rotation == 1 || rotation == -1) {
+        op_choice = rotation == 1 ? 1 : 2;
+        size2[0] = sc2[2];
+        size2[2] = sc2[0];
+    }
+    const long long sx = size[0], sy = size[1], sz = size[2];
+    const size_t total = (size_t)sx * sy * sz;
+
+    cli::Volume psf1 = cli::load_tiff(psf1_path), psf2 = cli::load_tiff(psf2_path), bp1, bp2;
+    if (!cli::same_size(psf1, psf2)) { printf("\tThe two PSFs don't have the same image size, processing stopped !!!\n"); return 1; }
+    if (unmatch) { bp1 = cli::load_tiff(argv[35]); bp2 = cli::load_tiff(argv[36]); }
+    else { bp1.data.resize(psf1.count()); bp2.data.resize(psf1.count()); }
+
+    // ---- registration set-up (:530-561): initial matrix choice -> regChoice; the batch hard-codes affMethod 6
+    int reg_choice = 2;
+    bool have_itmx = false;
+    switch (initial) {
+    case 1: have_itmx = true; break;
+    case 2: reg_choice = 3; break;
+    case 3: reg_choice = 4; break;
+    default: break;
+    }
+    const int aff_method = 6;
+    const float cost_bar = 0.1f;
+    float tmx[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, initial_tmx[12], previous[12], weighted[12];
+    if (have_itmx) {
+        FILE *f = fopen(itmx_path.c_str(), "r");
+        if (!f) { printf("***** Input transformation matrix file does not exist: %s\n", itmx_path.c_str()); return 1; }
+        for (int i = 0; i < 12; ++i)
+            if (fscanf(f, "%f", &tmx[i]) != 1) { printf("***** Malformed matrix file %s\n", itmx_path.c_str()); fclose(f); return 1; }
+        fclose(f);
+    }
+    std::memcpy(previous, tmx, sizeof tmx);
+    std::memcpy(weighted, tmx, sizeof tmx);
+
+    std::vector<float> b_reg(total), decon(total), mp((size_t)(sx * sy + sy * sz + sz * sx));
+    float reg_records[11] = {0}, decon_records[10] = {0};
+    const auto t_batch = std::chrono::steady_clock::now();
+    auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+    log("\n=== spimFusionBatch: images %d .. %d (step %d), size %lld x %lld x %lld, regMode %d, %d decon iterations\n",
+        n_start, n_end, n_step, sx, sy, sz, reg_mode, iters);
+
+    bool first = true;
+    for (int n = n_start; n <= n_end; n += n_step) {
+        int reg_choice_now = reg_choice;
+        if (reg_mode == 0) reg_choice_now = 0;          // :614-616
+        else if (reg_mode == 1) n = n_test;             // :617-619: register on the test image first
+        log("\n*** Image time point number: %d \n", n);
+        const auto t0 = std::chrono::steady_clock::now();
+
+        // ---- preprocessing (:666-711)
+        cli::Volume a_in = cli::load_tiff(name_of(dir1, base1, n)), b_in = cli::load_tiff(name_of(dir2, base2, n));
+        if (a_in.size[0] != in1[0] || a_in.size[1] != in1[1] || a_in.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); return 1; }
+        if (b_in.size[0] != in2[0] || b_in.size[1] != in2[1] || b_in.size[2] != in2[2]) { printf("\t Input image 2 size does not match !!!\n"); return 1; }
+        cli::Volume a = a_in;
+        if (a.size[0] != size[0] || a.size[1] != size[1] || a.size[2] != size[2]) {
+            a.data.resize(total);
+            for (int i = 0; i < 3; ++i) a.size[i] = size[i];
+            (void)imresize3d(a.data.data(), a_in.data.data(), sx, sy, sz, a_in.size[0], a_in.size[1], a_in.size[2], device);
+        }
+        cli::Volume b_rot = b_in;
+        if (op_choice != 0) (void)imoperation3D(b_rot.data.data(), b_rot.size, b_in.data.data(), b_in.size, op_choice, device);
+        cli::Volume b = b_rot;
+        if (b.size[0] != size2[0] || b.size[1] != size2[1] || b.size[2] != size2[2]) {
+            b.data.resize((size_t)size2[0] * size2[1] * size2[2]);
+            for (int i = 0; i < 3; ++i) b.size[i] = size2[i];
+            (void)imresize3d(b.data.data(), b_rot.data.data(), size2[0], size2[1], size2[2], b_rot.size[0], b_rot.size[1],
+                             b_rot.size[2], device);
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+
+        // ---- registration with the reference's fall-back ladder (:714-843)
+        std::fill(b_reg.begin(), b_reg.end(), 0.f);
+        if (have_itmx) std::memcpy(initial_tmx, tmx, sizeof tmx);
+        auto run = [&](int choice, bool use_input) {
+            return reg3d(b_reg.data(), tmx, a.data.data(), b.data.data(), a.size, b.size, choice, aff_method, use_input, ftol,
+                         it_limit, device, -1, true, reg_records);
+        };
+        auto bad = [&] { return !checkmatrix(tmx, sx, sy, sz) || reg_records[3] < cost_bar; };
+        auto ladder = [&] {  // first attempt, other scheme without the input matrix, then the input matrix itself
+            (void)run(reg_choice_now, have_itmx);
+            if (bad()) {
+                log("\n\t... Attempt failed: transformation matrix problematic or cost function value %f < threshold %2.2f\n"
+                    "\n\t... Change scheme and redo the registration!!!\n", reg_records[3], cost_bar);
+                (void)run(reg_choice_now == 4 ? 2 : 4, false);
+                if (bad() && have_itmx) {
+                    log("\n\t... Attempt failed again: use input transformation matrix!!!\n");
+                    std::memcpy(tmx, initial_tmx, sizeof tmx);
+                    (void)run(0, true);
+                }
+            }
+        };
+        bool restart_batch = false;
+        switch (reg_mode) {
+        case 0: (void)run(0, have_itmx); break;
+        case 1:  // register on the test image, then apply that matrix to every image (:719-751)
+            ladder();
+            reg_mode = 0;
+            have_itmx = true;
+            restart_batch = true;
+            break;
+        case 2:
+            if (first) {
+                ladder();
+                std::memcpy(weighted, tmx, sizeof tmx);
+            } else {  // start from the running average, fall back to the previous matrix (:786-808)
+                have_itmx = true;
+                std::memcpy(tmx, weighted, sizeof tmx);
+                (void)run(2, true);
+                if (bad()) {
+                    log("\n\t... Attempt failed: use previous transformation matrix!!!\n");
+                    std::memcpy(tmx, previous, sizeof tmx);
+                    (void)run(0, true);
+                }
+                for (int j = 0; j < 12; ++j) weighted[j] = (float)(0.8 * weighted[j] + 0.2 * tmx[j]);  // double arithmetic, :805-807
+            }
+            std::memcpy(previous, tmx, sizeof tmx);
+            break;
+        case 3:
+            if (have_itmx) std::memcpy(tmx, initial_tmx, sizeof tmx);
+            ladder();
+            break;
+        default: printf("\tWrong registration mode %d, processing stopped !!!\n", reg_mode); return 1;
+        }
+        first = false;
+        if (restart_batch) { n = n_start - n_step; continue; }
+        log("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
+            reg_records[1], reg_records[3], reg_records[7]);
+        const std::string ns = std::to_string(n);
+        write_tmx(tmx_dir + "Matrix_" + ns + ".tmx", tmx);  // always saved (:859-868)
+        if (save_reg1) writetifstack(const_cast<char *>((reg1_dir + base1 + "reg_" + ns + ".tif").c_str()), a.data.data(), size, (unsigned short)in_bits);
+        if (save_reg2) writetifstack(const_cast<char *>((reg2_dir + base2 + "reg_" + ns + ".tif").c_str()), b_reg.data(), size, (unsigned short)in_bits);
+        const auto t2 = std::chrono::steady_clock::now();
+
+        // ---- joint deconvolution (:874-911)
+        std::fill(decon.begin(), decon.end(), 0.f);
+        (void)decon_dualview(decon.data(), a.data.data(), b_reg.data(), size, psf1.data.data(), psf2.data.data(), psf1.size, false,
+                             iters, device, -1, true, decon_records, unmatch, bp1.data.data(), bp2.data.data());
+        log("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
+            decon_records[5]);
+        writetifstack(const_cast<char *>((decon_dir + "Decon_" + ns + ".tif").c_str()), decon.data(), size, out_bits);
+        const auto t3 = std::chrono::steady_clock::now();
+
+        // ---- projections (:913-943)
+        if (save_zproj || save_xproj || save_yproj) {
+            unsigned int mp_size[6];
+            (void)mp2dgpu(mp.data(), mp_size, decon.data(), size, save_zproj, save_xproj, save_yproj);
+            unsigned int s2[3] = {0, 0, 1};
+            if (save_zproj) { s2[0] = mp_size[0]; s2[1] = mp_size[1]; writetifstack(const_cast<char *>((mp_xy + "MP_XY_" + ns + ".tif").c_str()), mp.data(), s2, out_bits); }
+            if (save_xproj) { s2[0] = mp_size[2]; s2[1] = mp_size[3]; writetifstack(const_cast<char *>((mp_yz + "MP_YZ_" + ns + ".tif").c_str()), mp.data() + sx * sy, s2, out_bits); }
+            if (save_yproj) { s2[0] = mp_size[4]; s2[1] = mp_size[5]; writetifstack(const_cast<char *>((mp_zx + "MP_ZX_" + ns + ".tif").c_str()), mp.data() + sx * sy + sy * sz, s2, out_bits); }
+        }
+        for (int axis = 1; axis <= 2; ++axis) {
+            if (!(axis == 1 ? save_3dx : save_3dy)) continue;
+            const long long project_num = 36;
+            const long long rot = (long long)std::llround(std::sqrt(axis == 1 ? (double)(sy * sy + sz * sz) : (double)(sx * sx + sz * sz)));
+            std::vector<float> mp3d((size_t)((axis == 1 ? sx : sy) * rot * project_num));
+            unsigned int s3[3];
+            (void)mip3dgpu(mp3d.data(), s3, decon.data(), size, axis, project_num);
+            writetifstack(const_cast<char *>(((axis == 1 ? mp_3dx + "MP_3D_Xaxis_" : mp_3dy + "MP_3D_Yaxis_") + ns + ".tif").c_str()),
+                          mp3d.data(), s3, out_bits);
+        }
+        const auto t4 = std::chrono::steady_clock::now();
+        log("\tTime cost: preprocessing %2.3f s, registration %2.3f s, deconvolution %2.3f s, projections %2.3f s\n", sec(t0, t1),
+            sec(t1, t2), sec(t2, t3), sec(t3, t4));
+    }
+    log("\n=== Batch processing completed, whole time cost: %2.3f s\n", sec(t_batch, std::chrono::steady_clock::now()));
+    return 0;
+}

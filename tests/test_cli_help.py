@@ -41,3 +41,12 @@ def test_bad_memory_mode_is_rejected_before_any_io():
 def test_missing_value_is_an_error():
     r = subprocess.run([os.path.join(BIN, "reg3D"), "-it"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0
+
+
+def test_batch_tool_argument_count():
+    exe = os.path.join(BIN, "spimFusionBatch")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "-h"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "34:" in r.stdout and "35, 36" in r.stdout
+    r = subprocess.run([exe, "a", "b", "c"], capture_output=True, text=True, timeout=60)
+    assert "Arguments do NOT match" in r.stdout

@@ -148,3 +148,50 @@ def test_spimFusion_cli(tmp_path, which):
     assert np.array_equal(got, want)
     m_file = np.array([float(v) for v in open(otmx).read().split()[:12]], dtype=np.float32)
     assert np.allclose(m_file, tmx, atol=1e-5)
+
+
+def _batch_args(tmp_path, out, reg_mode, initial="0", itmx="none"):
+    return [str(out) + "/", str(tmp_path / "SPIMA") + "/", str(tmp_path / "SPIMB") + "/", "SPIMA_", "SPIMB_", "0", "2", "1", "1",
+            "1", "1", "1", "1", "1", "1", str(reg_mode), "0", initial, itmx, "0.001", "150", "0", "1", str(tmp_path / "pa.tif"),
+            str(tmp_path / "pb.tif"), "3", "0", "0", "1", "0", "0", "32", "0", "0"]
+
+
+def _make_series(tmp_path):
+    from microimagelib_amd import api
+    psf_a = do.gaussian_psf((7, 7, 7), (1.5, 1.0, 1.0))
+    psf_b = do.gaussian_psf((7, 7, 7), (1.0, 1.0, 1.5))
+    os.makedirs(tmp_path / "SPIMA", exist_ok=True)
+    os.makedirs(tmp_path / "SPIMB", exist_ok=True)
+    api.writetifstack(str(tmp_path / "pa.tif"), psf_a, 32)
+    api.writetifstack(str(tmp_path / "pb.tif"), psf_b, 32)
+    for t in range(3):
+        api.writetifstack(str(tmp_path / "SPIMA" / f"SPIMA_{t}.tif"),
+                          do.synthetic_view((16, 32, 32), psf_a, seed=t, noise_seed=10 + t, n_blobs=10), 32)
+        api.writetifstack(str(tmp_path / "SPIMB" / f"SPIMB_{t}.tif"),
+                          do.synthetic_view((16, 32, 32), psf_b, seed=t, noise_seed=20 + t, n_blobs=10), 32)
+
+
+@pytest.mark.parametrize("reg_mode", [3, 1, 2])
+def test_spimFusionBatch_ours_equals_reference_main(tmp_path, reg_mode):
+    """Our spimFusionBatch main and the reference's main, both on our libapi.so, produce identical outputs
+    (Decon stacks, matrix files, Z projections) for the independent, register-once and chained registration modes."""
+    from microimagelib_amd import api
+    ours, ref = _need("spimFusionBatch", "ours"), _need("spimFusionBatch", "reference")
+    _make_series(tmp_path)
+    outs = {}
+    for name, exe in (("ours", ours), ("ref", ref)):
+        out = tmp_path / f"out_{name}"
+        r = subprocess.run([exe] + _batch_args(tmp_path, out, reg_mode), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = out
+    for t in range(3):
+        a = api.readtifstack(str(outs["ours"] / "Decon" / f"Decon_{t}.tif"))
+        b = api.readtifstack(str(outs["ref"] / "Decon" / f"Decon_{t}.tif"))
+        assert np.array_equal(a, b), t
+        ma = open(outs["ours"] / "TMX" / f"Matrix_{t}.tmx").read().split()
+        mb = open(outs["ref"] / "TMX" / f"Matrix_{t}.tmx").read().split()
+        assert [float(v) for v in ma] == [float(v) for v in mb]
+        mip = api.readtifstack(str(outs["ours"] / "Decon" / "MP_ZProj" / f"MP_XY_{t}.tif"))
+        assert np.array_equal(mip[0], np.maximum(a.max(axis=0), 0))
+        assert os.path.exists(outs["ours"] / "RegB" / f"SPIMB_reg_{t}.tif")
+    assert "Image time point number" in open(outs["ours"] / "ProcessingLog.txt").read()
