@@ -102,6 +102,28 @@ def reg3d(target, source, i_tmx=None, reg_choice=2, aff_method=6, input_tmx=Fals
     return out, tmx, rec
 
 
+def reg2d(target, source, i_tmx=None, reg_choice=2, input_tmx=False, ftol=1e-4, it_limit=3000, device=0,
+          gpu_mem_mode=1, verbose=False):
+    """``reg2d`` (reference include/libapi.h:24-25) on [h][w] images.  Returns (registered, tmx[6], records[11])."""
+    lib = _lib.load()
+    target = np.ascontiguousarray(target, dtype=np.float32)
+    source = np.ascontiguousarray(source, dtype=np.float32)
+    if target.ndim != 2 or source.ndim != 2:
+        raise ValueError("expected 2-D images [y][x]")
+    tmx = np.zeros(6, dtype=np.float32)
+    if i_tmx is not None:
+        tmx[:] = np.asarray(i_tmx, dtype=np.float32).reshape(6)
+    out = np.zeros_like(target)
+    rec = np.zeros(11, dtype=np.float32)
+    s1 = (C.c_uint * 3)(target.shape[1], target.shape[0], 1)
+    s2 = (C.c_uint * 3)(source.shape[1], source.shape[0], 1)
+    rc = lib.reg2d(_fp(out), _fp(tmx), _fp(target), _fp(source), s1, s2, int(reg_choice), bool(input_tmx), float(ftol),
+                   int(it_limit), int(device), int(gpu_mem_mode), bool(verbose), _fp(rec))
+    if rc != 0:
+        raise LibApiError("reg2d", rc)
+    return out, tmx, rec
+
+
 def atrans3dgpu(source, tmx, out_shape, device=0):
     """``atrans3dgpu`` (reference include/libapi.h:30)."""
     lib = _lib.load()

@@ -102,6 +102,8 @@ __device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int
 }
 
 // affinetransformkernel, reference include/cukernel.cuh:501-524 (window 0 <= t < s2).
+// STRICT: the 2-D variant tests 0 < t (affineTransform2Dkernel, include/cukernel.cuh:558-573).
+template <bool STRICT>
 __global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restrict__ out,
                                                                const float *__restrict__ src, AffineArgs a) {
     const int x = blockIdx.x * kTileX + (threadIdx.x & (kTileX - 1));
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restri
     const float ty = coord(a.m + 4, ix, iy, iz);
     const float tz = coord(a.m + 8, ix, iy, iz);
     float v = 0.0f;
-    if (tx >= 0 && tx < (float)a.sx && ty >= 0 && ty < (float)a.sy && tz >= 0 && tz < (float)a.sz)
+    const bool lower = STRICT ? (tx > 0 && ty > 0 && tz > 0) : (tx >= 0 && ty >= 0 && tz >= 0);
+    if (lower && tx < (float)a.sx && ty < (float)a.sy && tz < (float)a.sz)
         v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
     out[(size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z)] = v;
 }
@@ -230,11 +233,13 @@ AffineArgs make_args(Dims t, Dims s, const Affine12 &m) {
 
 }  // namespace
 
-void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s) {
+void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s,
+                     bool strict_window) {
     AffineArgs a = make_args(out_dims, src_dims, m);
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, a.tz);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "affine_resample: volume exceeds launch limits");
-    hipLaunchKernelGGL(resample_kernel, grid, dim3(kBlockThreads), 0, s, out, src, a);
+    if (strict_window) hipLaunchKernelGGL(resample_kernel<true>, grid, dim3(kBlockThreads), 0, s, out, src, a);
+    else hipLaunchKernelGGL(resample_kernel<false>, grid, dim3(kBlockThreads), 0, s, out, src, a);
     MIL_HIP(hipGetLastError());
 }
 

@@ -149,8 +149,45 @@ extern "C" int reg_3dgpu(float *h_reg, float *iTmx, float *h_img1, float *h_img2
     return status;
 }
 
-extern "C" int reg2d(float *, float *, float *, float *, unsigned int *, unsigned int *, int, bool, float, int, int,
-                     int, bool, float *) {
-    printf("\n ****reg2d (2-D registration) is outside the hot path and not provided by this build **** \n");
-    return -1;
+extern "C" int reg2d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1, unsigned int *imSize2,
+                     int regChoice, bool flagTmx, float FTOL, int itLimit, int deviceNum, int gpuMemMode, bool verbose,
+                     float *records) {
+    // reference src/api_reg.cpp:115-244.  iTmx: 6 floats (a0 a1 tx; a3 a4 ty); records: 11 floats.
+    if (gpuMemMode == 0) {
+        printf("\n **** 2D CPU registration is currently not supported !!! **** \n");
+        return regChoice >= 0 && regChoice <= 2 ? 0 : 1;  // the reference prints and returns 0 for choices 0..2 (:170-181)
+    }
+    if (gpuMemMode != 1) {
+        printf("\n****Wrong gpuMemMode setup, no deconvolution performed !!! ****\n");
+        return 1;  // :226-228
+    }
+    if (regChoice < 0 || regChoice > 3) {
+        printf("\n ****Wrong registration choice is setup, no registraiton performed !!! **** \n");
+        return 1;  // :221-223
+    }
+    return guarded("reg2d", [&]() -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        MIL_HIP(hipSetDevice(deviceNum));
+        records[8] = free_mb();
+        records[0] = (float)gpuMemMode;
+        const int w1 = (int)imSize1[0], h1 = (int)imSize1[1], w2 = (int)imSize2[0], h2 = (int)imSize2[1];
+        if (regChoice == 3 && (w1 != w2 || h1 != h2)) {
+            printf("\n ****Image size of the 2D images is not matched, processing stop !!! **** \n");
+            return 1;  // :208-211
+        }
+        StreamGuard sg;
+        const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
+        DeviceBuffer<float> d1(n1), d2(n2), d_reg(n1);
+        MIL_HIP(hipMemcpyAsync(d1.get(), h_img1, n1 * sizeof(float), hipMemcpyHostToDevice, sg.s));
+        MIL_HIP(hipMemcpyAsync(d2.get(), h_img2, n2 * sizeof(float), hipMemcpyHostToDevice, sg.s));
+        records[9] = free_mb();
+        const bool writes_output = !(regChoice == 0 && !flagTmx);  // choice 0 without a matrix does nothing upstream
+        reg2d_device(d_reg.get(), iTmx, d1.get(), d2.get(), w1, h1, w2, h2, regChoice, flagTmx, FTOL, itLimit, records, sg.s);
+        if (writes_output) MIL_HIP(hipMemcpyAsync(h_reg, d_reg.get(), n1 * sizeof(float), hipMemcpyDeviceToHost, sg.s));
+        MIL_HIP(hipStreamSynchronize(sg.s));
+        records[10] = free_mb();
+        records[7] = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (verbose) printf("Total time cost for whole processing is %2.3f s\n", records[7]);
+        return 0;
+    });
 }

@@ -76,8 +76,9 @@ struct Affine12 {
     float m[12];
 };
 // out[x,y,z] = trilinear(src, M*(x,y,z,1)) inside the window, 0 outside.
+// strict_window: lower bound 0 < t instead of 0 <= t (the reference's 2-D transform kernel).
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m,
-                     hipStream_t s);
+                     hipStream_t s, bool strict_window = false);
 struct CorrWorkspace {
     DeviceBuffer<double> partials;  // 2 * kMaxCorrBlocks
     double *host = nullptr;         // pinned: {sum s*s, sum s*t}

@@ -42,6 +42,10 @@ void matrixmultiply(float *m, const float *a, const float *b) {
 
 namespace {
 
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void set_identity(float *m) {
     for (int i = 0; i < 12; ++i) m[i] = 0.f;
     m[0] = m[5] = m[10] = 1.f;
@@ -124,43 +128,53 @@ bool check_matrix(const float *m, long long sx, long long sy, long long sz) {
 // ---------------------------------------------------------------------------
 namespace {
 
-// reg2d_shiftalign1 (x_only = false) / reg2d_shiftalignX1 (x_only = true) on device-resident images of equal size
-// w x h.  aff6 = (a0 a1 tx; a3 a4 ty) in/out.  A 2-D image is handled as a one-plane volume: with a zero z column
-// the 3-D coordinate expression adds exact zeros, so the arithmetic is that of corr2Dkernel.
-void shift_align_2d(float aff6[6], const float *d_img1, const float *d_img2, int w, int h, bool x_only,
-                    k::ReduceWorkspace &red, k::CorrWorkspace &corr, hipStream_t s) {
-    const Dims d{w, h, 1};
-    const size_t n = (size_t)w * h;
-    DeviceBuffer<float> t_ms(n), s_ms(n);
-    const double sum1 = k::reduce_sync(k::kSum, d_img1, n, 0.f, red, s);
-    k::add_value(t_ms.get(), d_img1, -((float)sum1 / (float)n), n, s);
-    const float sd_t = (float)std::sqrt(k::reduce_sync(k::kSumSqShifted, t_ms.get(), n, 0.f, red, s));
-    if (sd_t == 0.f) throw Error(-3, "2-D MIP registration: SD of the target projection is zero (empty image)");
-    const double sum2 = k::reduce_sync(k::kSum, d_img2, n, 0.f, red, s);
-    k::add_value(s_ms.get(), d_img2, -((float)sum2 / (float)n), n, s);
-
-    auto zncc = [&](const float *a) -> float {  // -costfunc2D, src/api_subfunc.cu:1815-1821 + corrfunc2D :1014-1036
-        k::Affine12 m = {{a[0], a[1], 0.f, a[2], a[3], a[4], 0.f, a[5], 0.f, 0.f, 1.f, 0.f}};
+// Mean-subtracted pair and the 2-D ZNCC (-costfunc2D, reference src/api_subfunc.cu:1815-1821 + corrfunc2D :1014-1036).
+// A 2-D image is a one-plane volume: with a zero z column the 3-D coordinate expression adds exact zeros, so the
+// arithmetic is that of corr2Dkernel.
+struct Cost2d {
+    Dims d1, d2;
+    DeviceBuffer<float> t_ms, s_ms;
+    float sd_t = 0.f;
+    k::CorrWorkspace corr;
+    hipStream_t s;
+    Cost2d(const float *d_img1, const float *d_img2, int w1, int h1, int w2, int h2, k::ReduceWorkspace &red, hipStream_t st)
+        : d1{w1, h1, 1}, d2{w2, h2, 1}, t_ms((size_t)w1 * h1), s_ms((size_t)w2 * h2), s(st) {
+        const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
+        const double sum1 = k::reduce_sync(k::kSum, d_img1, n1, 0.f, red, s);
+        k::add_value(t_ms.get(), d_img1, -((float)sum1 / (float)n1), n1, s);
+        sd_t = (float)std::sqrt(k::reduce_sync(k::kSumSqShifted, t_ms.get(), n1, 0.f, red, s));
+        if (sd_t == 0.f) throw Error(-3, "2-D registration: SD of image 1 is zero (empty image)");
+        const double sum2 = k::reduce_sync(k::kSum, d_img2, n2, 0.f, red, s);
+        k::add_value(s_ms.get(), d_img2, -((float)sum2 / (float)n2), n2, s);
+    }
+    static k::Affine12 lift(const float *a) {
+        return k::Affine12{{a[0], a[1], 0.f, a[2], a[3], a[4], 0.f, a[5], 0.f, 0.f, 1.f, 0.f}};
+    }
+    float zncc(const float *a6) {
         double ss = 0, st = 0;
-        k::corr_sums_sync(t_ms.get(), s_ms.get(), d, d, m, corr, s, &ss, &st, /*float_products=*/true);
+        k::corr_sums_sync(t_ms.get(), s_ms.get(), d1, d2, lift(a6), corr, s, &ss, &st, /*float_products=*/true);
         if (std::sqrt(ss) == 0) return -2.0f;
         return (float)(st / std::sqrt(ss)) / sd_t;
-    };
-    const float shift_region = 0.3f, total_step = 30.f;  // src/api_reg.cpp:463-464
+    }
+};
+
+// reg2d_shiftalign1 (x_only = false) / reg2d_shiftalignX1 (x_only = true), reference src/api_subfunc.cu:1860-2120:
+// exhaustive search of the translation on a (2*total_step)^2 (or 2*total_step) grid.  aff6 = (a0 a1 tx; a3 a4 ty) in/out.
+void shift_align_2d(float aff6[6], Cost2d &cost, int w2, int h2, bool x_only, float shift_region, float total_step) {
     float p[6];
     std::memcpy(p, aff6, sizeof p);
     const float off_x = p[2], off_y = p[5];
-    const float step_x = (float)w * shift_region / total_step, step_y = (float)h * shift_region / total_step;
+    const float step_x = (float)w2 * shift_region / total_step, step_y = (float)h2 * shift_region / total_step;
     float best = 0.f, best_x = 0.f, best_y = 0.f;
     for (int i = -(int)total_step; i < (int)total_step; ++i) {
         p[2] = off_x + step_x * (float)i;
         if (x_only) {
-            const float c = zncc(p);
+            const float c = cost.zncc(p);
             if (c > best) { best = c; best_x = p[2]; }
         } else {
             for (int j = -(int)total_step; j < (int)total_step; ++j) {
                 p[5] = off_y + step_y * (float)j;
-                const float c = zncc(p);
+                const float c = cost.zncc(p);
                 if (c > best) { best = c; best_x = p[2]; best_y = p[5]; }
             }
         }
@@ -176,18 +190,93 @@ void mip_shift_search(float shift[3], const float *d_img1, const float *d_img2, 
     const size_t nxy = (size_t)dims.nx * dims.ny, nzx = (size_t)dims.nz * dims.nx;
     DeviceBuffer<float> p1(nxy > nzx ? nxy : nzx), p2(nxy > nzx ? nxy : nzx);
     k::ReduceWorkspace red;
-    k::CorrWorkspace corr;
     k::max_projection(p1.get(), d_img1, dims, 1, stream);  // [ny][nx]
     k::max_projection(p2.get(), d_img2, dims, 1, stream);
+    const float shift_region = 0.3f, total_step = 30.f;  // src/api_reg.cpp:463-464
     float t1[6] = {1, 0, 0, 0, 1, 0};
-    shift_align_2d(t1, p1.get(), p2.get(), (int)dims.nx, (int)dims.ny, false, red, corr, stream);
+    {
+        Cost2d cost(p1.get(), p2.get(), (int)dims.nx, (int)dims.ny, (int)dims.nx, (int)dims.ny, red, stream);
+        shift_align_2d(t1, cost, (int)dims.nx, (int)dims.ny, false, shift_region, total_step);
+    }
     k::max_projection(p1.get(), d_img1, dims, 2, stream);  // width nz, height nx
     k::max_projection(p2.get(), d_img2, dims, 2, stream);
     float t2[6] = {1, 0, 0, 0, 1, t1[2]};
-    shift_align_2d(t2, p1.get(), p2.get(), (int)dims.nz, (int)dims.nx, true, red, corr, stream);
+    {
+        Cost2d cost(p1.get(), p2.get(), (int)dims.nz, (int)dims.nx, (int)dims.nz, (int)dims.nx, red, stream);
+        shift_align_2d(t2, cost, (int)dims.nz, (int)dims.nx, true, shift_region, total_step);
+    }
     shift[0] = t1[2];
     shift[1] = t1[5];
     shift[2] = t2[2];
+}
+
+// reg2d, reference src/api_reg.cpp:115-244 with reg2d_affine1 (src/api_subfunc.cu:2233-2336), reg2d_shiftalign1 and
+// reg2d_phasor1, on device-resident images.
+int reg2d_device(float *d_reg, float *aff6, const float *d_img1, const float *d_img2, int w1, int h1, int w2, int h2,
+                 int reg_choice, bool flag_tmx, float ftol, int it_limit, float *records, hipStream_t stream) {
+    const Dims d1{w1, h1, 1}, d2{w2, h2, 1};
+    k::ReduceWorkspace red;
+    float a[6];
+    if (flag_tmx) std::memcpy(a, aff6, sizeof a);
+    else {  // centred placement (:2279-2280)
+        a[0] = 1; a[1] = 0; a[2] = (float)((w2 - w1) / 2);
+        a[3] = 0; a[4] = 1; a[5] = (float)((h2 - h1) / 2);
+    }
+    auto resample = [&](const float *m6) {
+        k::affine_resample(d_reg, d_img2, d1, d2, Cost2d::lift(m6), stream, /*strict_window=*/true);
+        MIL_HIP(hipStreamSynchronize(stream));
+    };
+    switch (reg_choice) {
+    case 0:  // apply the input matrix (only with an input matrix, :189-194)
+        if (flag_tmx) {
+            Cost2d cost(d_img1, d_img2, w1, h1, w2, h2, red, stream);
+            records[1] = cost.zncc(a);
+            records[3] = records[1];
+            resample(a);
+        }
+        return 0;
+    case 1: {  // translation grid search, 0.4 of the extent in 40 steps (:196-203)
+        Cost2d cost(d_img1, d_img2, w1, h1, w2, h2, red, stream);
+        shift_align_2d(a, cost, w2, h2, false, 0.4f, 40.f);
+        std::memcpy(aff6, a, sizeof a);
+        resample(a);
+        return 0;
+    }
+    case 2: {  // 6-parameter Powell on the 2-D ZNCC (:204-206)
+        Cost2d cost(d_img1, d_img2, w1, h1, w2, h2, red, stream);
+        float last[6], xi[36];
+        std::memcpy(last, a, sizeof a);
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) xi[i * 6 + j] = (i == j) ? 1.f : 0.f;
+        int evals = 0;
+        CostFn f = [&](const float *x) -> float {  // costfunc2D: remembers the matrix of the LAST evaluation
+            std::memcpy(last, x, sizeof last);
+            ++evals;
+            return -cost.zncc(x);
+        };
+        records[1] = -f(a);
+        evals = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        const PowellResult r = powell_minimize(a, xi, 6, 6, ftol, f, &evals, it_limit);
+        std::memcpy(aff6, last, sizeof last);
+        records[3] = -r.fret;
+        records[5] = (float)evals;
+        records[6] = (float)seconds_since(t0);
+        resample(last);
+        return 0;
+    }
+    case 3: {  // pixel-level phasor shift (:207-220)
+        if (w1 != w2 || h1 != h2) throw Error(1, "reg2d: image sizes differ, phasor registration needs equal sizes");
+        long long sh[3];
+        phasor_shift(sh, d_img1, d_img2, d1, stream);
+        k::shift_volume(d_reg, d_img2, d1, -sh[0], -sh[1], 0, false, stream);
+        MIL_HIP(hipStreamSynchronize(stream));
+        aff6[0] = 1; aff6[1] = 0; aff6[2] = (float)sh[0];
+        aff6[3] = 0; aff6[4] = 1; aff6[5] = (float)sh[1];
+        return 0;
+    }
+    default: throw Error(1, "reg2d: regChoice must be 0..3");
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -289,13 +378,6 @@ void phasor_shift(long long shift[3], const float *d_img1, const float *d_img2, 
 // ---------------------------------------------------------------------------
 // driver
 // ---------------------------------------------------------------------------
-namespace {
-
-double seconds_since(std::chrono::steady_clock::time_point t0) {
-    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-}
-
-}  // namespace
 
 int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, Dims dims,
                         int aff_method, bool flag_tmx, float ftol, int it_limit, bool verbose, float *records,

@@ -33,6 +33,12 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
 // then 60 steps of the z shift on the y projections with the x shift held.  shift = {x, y, z} in voxels.
 void mip_shift_search(float shift[3], const float *d_img1, const float *d_img2, Dims dims, hipStream_t stream);
 
+// reg2d on device-resident images (w x h, x fastest): regChoice 0 apply aff6 | 1 translation grid search |
+// 2 6-parameter Powell | 3 phasor shift.  aff6 = (a0 a1 tx; a3 a4 ty), target pixel -> source coordinate, in/out.
+// records: >= 8 floats ([1], [3], [5], [6] written where the reference writes them).
+int reg2d_device(float *d_reg, float *aff6, const float *d_img1, const float *d_img2, int w1, int h1, int w2, int h2,
+                 int reg_choice, bool flag_tmx, float ftol, int it_limit, float *records, hipStream_t stream);
+
 // 3-D phasor pre-registration of regChoice 1 / 3, reference reg3d_phasor1 (src/api_subfunc.cu:2465-2590): peak of the
 // inverse transform of the normalised cross-power spectrum, with the reference's wrap-around disambiguation by the
 // ZNCC of the overlapping crops.  shift = {x, y, z}: source(p) ~ target(p - shift).

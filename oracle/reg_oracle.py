@@ -490,3 +490,60 @@ def reg3d_phasor(target, source):
             if ind[d] == 1:
                 shift[d] = shift[d] - dims[d] if shift[d] > 0 else shift[d] + dims[d]
     return np.array(shift, dtype=np.int64)
+
+
+# ---------------------------------------------------------------- 2-D registration (reg2d)
+def affine_transform_2d(src, a6, out_shape):
+    """affineTransform2Dkernel, include/cukernel.cuh:558-573: strict window 0 < t < s2 (unlike the 3-D kernel)."""
+    src = np.asarray(src, dtype=f32)[None]
+    tx, ty, tz = _coords(_matrix_2d(a6), (1,) + tuple(out_shape))
+    valid = (tx > 0) & (tx < f32(src.shape[2])) & (ty > 0) & (ty < f32(src.shape[1]))
+    return np.where(valid, _trilinear(src, tx, ty, tz), f32(0)).astype(f32)[0]
+
+
+def reg2d(img1, img2, reg_choice, powell_fn=None, flag_tmx=False, i_tmx=None, ftol=1e-4, it_limit=3000):
+    """reg2d, src/api_reg.cpp:115-244 (GPU mode): 0 apply matrix | 1 translation grid (0.4, 40 steps) |
+    2 6-parameter Powell (reg2d_affine1, src/api_subfunc.cu:2233-2336) | 3 phasor shift.
+    Returns (registered, a6, records[11])."""
+    img1 = np.asarray(img1, dtype=f32)
+    img2 = np.asarray(img2, dtype=f32)
+    h1, w1 = img1.shape
+    h2, w2 = img2.shape
+    rec = np.zeros(11, dtype=f32)
+    if flag_tmx:
+        a = np.asarray(i_tmx, dtype=f32).copy()
+    else:
+        a = np.array([1, 0, (w2 - w1) // 2, 0, 1, (h2 - h1) // 2], dtype=f32)
+    if reg_choice == 0:
+        return (affine_transform_2d(img2, a, img1.shape) if flag_tmx else None), a, rec
+    if reg_choice == 1:
+        a, _ = shift_align_2d(img1, img2, tmx6=a, shift_region=0.4, total_step=40)
+        return affine_transform_2d(img2, a, img1.shape), a, rec
+    if reg_choice == 3:
+        sh = reg3d_phasor(img1[None], img2[None])
+        a = np.array([1, 0, sh[0], 0, 1, sh[1]], dtype=f32)
+        return imshift(img2[None], -int(sh[0]), -int(sh[1]), 0)[0], a, rec
+    if reg_choice != 2:
+        raise ValueError(reg_choice)
+    t_ms, _ = mean_subtract(img1)
+    sd_t = f32(np.sqrt(float(np.sum((t_ms * t_ms).astype(f32), dtype=np.float64))))
+    s_ms, _ = mean_subtract(img2)
+    last = a.copy()
+    counter = [0]
+
+    def cost(x):  # costfunc2D, 1-based vector
+        last[:] = x[1:7]
+        counter[0] += 1
+        return f32(-corrfunc2d(t_ms, sd_t, s_ms, last))
+
+    p = np.zeros(7, dtype=f32)
+    p[1:] = a
+    xi = np.zeros((7, 7), dtype=f32)
+    for i in range(1, 7):
+        xi[i, i] = 1
+    rec[1] = -cost(p)
+    counter[0] = 0
+    _, fret = powell_fn(p, xi, 6, f32(ftol), cost, counter, it_limit)
+    rec[3] = -fret
+    rec[5] = counter[0]
+    return affine_transform_2d(img2, last, img1.shape), last.copy(), rec

@@ -233,3 +233,29 @@ def test_reg3d_regchoice1_and_3():
     # the matrix is that of Powell's LAST line-search trial (reference quirk), within Brent's tolerance of the optimum
     assert abs(tmx3[3] - 5) < 0.5 and abs(tmx3[7] + 3) < 0.5 and abs(tmx3[11] - 2) < 0.5, tmx3
     assert rec3[3] > 0.9, rec3
+
+
+# ---------------------------------------------------------------- reg2d
+def _pair_2d(shift=(3.3, -2.2)):
+    tgt = do.blob_volume((1, 48, 64), n_blobs=12, seed=5, background=0.0)[0]
+    a = np.array([1, 0, -shift[0], 0, 1, -shift[1]], dtype=np.float32)
+    return tgt, ro.affine_transform_2d(tgt, a, tgt.shape)
+
+
+@pytest.mark.parametrize("choice", [0, 1, 2, 3])
+def test_reg2d_matches_oracle(choice):
+    from microimagelib_amd import api
+    tgt, src = _pair_2d()
+    given = np.array([1, 0, 2.5, 0, 1, -1.5], dtype=np.float32)
+    powell = po.ref_powell if po.ref_available() else po.powell
+    use = choice == 0
+    reg, tmx, rec = api.reg2d(tgt, src, i_tmx=given if use else None, reg_choice=choice, input_tmx=use, ftol=1e-4,
+                              it_limit=500)
+    w_reg, w_tmx, w_rec = ro.reg2d(tgt, src, choice, powell_fn=powell, flag_tmx=use, i_tmx=given, ftol=1e-4, it_limit=500)
+    assert np.allclose(tmx, w_tmx, rtol=0, atol=1e-5), (tmx, w_tmx)
+    assert np.allclose(reg, w_reg, rtol=0, atol=1e-4 * float(np.max(np.abs(w_reg))))
+    if choice == 2:
+        assert rec[5] == w_rec[5] and abs(rec[3] - w_rec[3]) < 1e-5  # same evaluation count and optimum
+        assert rec[3] > rec[1]  # Powell improved the ZNCC (the 6-DOF optimum need not be the pure shift)
+    if choice in (1, 3):
+        assert abs(tmx[2] - 3.3) < 1.0 and abs(tmx[5] + 2.2) < 1.0
