@@ -259,3 +259,36 @@ def test_reg2d_matches_oracle(choice):
         assert rec[3] > rec[1]  # Powell improved the ZNCC (the 6-DOF optimum need not be the pure shift)
     if choice in (1, 3):
         assert abs(tmx[2] - 3.3) < 1.0 and abs(tmx[5] + 2.2) < 1.0
+
+
+# ---------------------------------------------------------------- benchmark size, properties only
+def test_full_size_registration_properties(dev):
+    """512x512x256 (BASELINE.json config 4): the oracle is too slow here, so size-independent properties.
+    Identity resample is exact; ZNCC of a volume with itself is 1; the cost is linear in a target scale and blind to a
+    target offset after mean removal; a known integer shift is what the cost prefers; Powell started at the optimum of
+    a self-registration stays there."""
+    import torch
+    shape = (256, 512, 512)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    vol = torch.rand(shape, device="cuda", generator=g) * 500 + 20
+    ident = np.eye(3, 4, dtype=np.float32).reshape(12)
+    assert torch.equal(dev.affine_resample(vol, ident, shape), vol)
+    ms = vol - vol.mean()
+    ss, st = dev.corr_sums(ms, ms, ident)
+    assert abs(st / ss - 1.0) < 1e-12 and ss > 0
+    ss2, st2 = dev.corr_sums(ms * 2.0, ms, ident)  # linear in the target
+    assert abs(ss2 - ss) <= 1e-12 * ss and abs(st2 - 2.0 * st) <= 1e-9 * abs(st)
+    shift = ident.copy()
+    shift[3], shift[7], shift[11] = 4.0, -3.0, 2.0
+    moved = dev.affine_resample(vol, shift, shape)  # moved(p) = vol(p + d)
+    back = ident.copy()
+    back[3], back[7], back[11] = -4.0, 3.0, -2.0
+    t_ms, m_ms = vol - vol.mean(), moved - moved.mean()
+
+    def zncc(m):
+        a, b = dev.corr_sums(t_ms, m_ms, m)
+        return b / np.sqrt(a)
+    assert zncc(back) > zncc(ident) and zncc(back) > zncc(shift)
+    reg, tmx, rec = dev.reg3d_affine(vol, vol, aff_method=1, it_limit=40)
+    assert rec[1] > 0.999999 and rec[3] >= rec[1] - 1e-6
+    assert np.allclose(tmx, ident, atol=0.05)
