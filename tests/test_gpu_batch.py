@@ -38,3 +38,34 @@ def test_fusion_pipeline_single_rank():
         floor = float(np.mean(np.abs(want)))
         assert float(np.max(np.abs(decons[t] - want) / np.maximum(np.abs(want), floor))) < 1e-5
         assert np.array_equal(stack[i].cpu().numpy(), np.maximum(decons[t].max(axis=0), 0))
+
+
+def test_fusion_pipeline_with_independent_registration():
+    """regMode 3 on one rank: every time point registered (3-DOF, regChoice 2) before the joint RL; the pipeline's
+    result equals the same calls through the host-pointer API."""
+    import torch
+    from microimagelib_amd import api, batch
+
+    shape = (32, 64, 64)
+    psf_a = do.gaussian_psf((9, 9, 9), (2.0, 1.2, 1.2))
+    psf_b = do.gaussian_psf((9, 9, 9), (1.2, 1.2, 2.0))
+    views = {t: (do.synthetic_view(shape, psf_a, seed=t, noise_seed=10 + t, n_blobs=12),
+                 do.synthetic_view(shape, psf_b, seed=t, noise_seed=20 + t, n_blobs=12)) for t in (4, 5)}
+    pipe = batch.FusionPipeline(shape, torch.from_numpy(psf_a).cuda(), torch.from_numpy(psf_b).cuda(), iters=3)
+    got = {}
+
+    def sink(t, decon, tmx, rec):
+        got[t] = (decon.cpu().numpy().copy(), tmx.copy(), rec.copy())
+
+    pol = batch.RegPolicy(reg_mode=3, reg_choice=2, aff_method=1, it_limit=60)
+    stack = batch.run_sharded([4, 5], lambda t: tuple(torch.from_numpy(v).cuda() for v in views[t]), pipe.fuse_pair, pol,
+                              pipe.reg_fn, pipe.check_fn, (shape[1], shape[2]), sink=sink, device="cuda")
+    pipe.close()
+    assert stack.shape == (2, shape[1], shape[2])
+    for t in (4, 5):
+        a, b = views[t]
+        b_reg, tmx, rec = api.reg3d(a, b, reg_choice=2, aff_method=1, it_limit=60)
+        want, _ = api.decon_dualview(a, b_reg, psf_a, psf_b, 3)
+        assert np.array_equal(got[t][1], tmx)
+        assert got[t][2][5] == rec[5]  # same number of cost evaluations
+        assert np.array_equal(got[t][0], want)

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 1500 python -m pytest tests/test_gpu_reg.py -x -q -k full_size 2>&1 | grep -E "passed|failed|^E " | head -30
+timeout 1500 python -m pytest tests/test_gpu_batch.py -x -q 2>&1 | grep -E "passed|failed|^E " | head -30
