@@ -250,6 +250,7 @@ struct ColArgs {
     // (z-conv works in place, so the partner's column 0 in S may already hold that row's RESULT.)
     float2 *col0;
     int col0_stride;  // ny
+    int ablate;       // timing experiments only (MIL_FX_ABLATE & 16: skip the OTF product, & 32: skip both z transforms)
 };
 
 template <int N, int NT>
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
         return;
     }
     if constexpr (kZ) {
-        if (packed) fft_dif<N, N, -1, kW + 1, NT, kWP>(tile, tw);  // 17 columns, same LDS stride
+        if (a.ablate & 32) {
+        } else if (packed) fft_dif<N, N, -1, kW + 1, NT, kWP>(tile, tw);  // 17 columns, same LDS stride
         else fft_dif<N, N, -1, kW, NT>(tile, tw);
     } else {
         fft_dif<N, N, -1, kW, NT>(tile, tw);
@@ -402,7 +404,8 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
                 }
             }
         }
-        if constexpr (kPrefetch) {
+        if (a.ablate & 16) {
+        } else if constexpr (kPrefetch) {
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 const int idx = j * NT + (int)threadIdx.x;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
             }
         }
         __syncthreads();
-        fft_dit<N, N, +1, kW, NT>(tile, tw);
+        if (!(a.ablate & 32)) fft_dit<N, N, +1, kW, NT>(tile, tw);
         tile_store<N, NT>(tile, base, a.row_stride);
     }
 }
@@ -809,6 +812,7 @@ void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s, bool reverse) cons
     a.groups = xs_ / kW;
     a.mode = inverse ? kColInverse : kColForward;
     a.reverse = reverse ? 1 : 0;
+    a.ablate = 0;
     dispatch_col((int)box_.ny, a, (long long)a.groups * box_.nz, s);
 }
 
@@ -823,6 +827,7 @@ void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s, bool reverse)
     a.groups = xs_ / kW;
     a.mode = kColConv;
     a.reverse = reverse ? 1 : 0;
+    a.ablate = ablate_;
     dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
 }
 
@@ -837,6 +842,7 @@ void ConvPlan::z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) con
     a.groups = xs_ / kW;
     a.mode = kColToOtf;
     a.reverse = 0;
+    a.ablate = 0;
     dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
 }
 
