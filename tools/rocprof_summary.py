@@ -32,7 +32,8 @@ def short(name):
 
 def counter_means(path, counter):
     acc = defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # newest run only (gpurun merges into an existing directory)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 a = acc[short(r["Kernel_Name"])]
@@ -42,7 +43,8 @@ def counter_means(path, counter):
 
 def main(src, dst):
     os.makedirs(dst, exist_ok=True)
-    for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True):
+    stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    for f in stats[-1:]:
         rows = list(csv.reader(open(f)))
         with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as out:
             w = csv.writer(out)
