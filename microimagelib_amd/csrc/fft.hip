@@ -648,10 +648,12 @@ std::vector<float2> twiddles(int n) {
     return t;
 }
 
+#ifdef MIL_FX_EXPERIMENTS
 int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+#endif
 
 // Column workgroups: LDS (N x 17 complex) caps long transforms at 1-3 workgroups per CU, so they get 512
 // threads to keep 16+ waves per CU in flight (measured at N = 512: 0.099 -> 0.092 ms per y pass);
@@ -768,7 +770,9 @@ ConvPlan::ConvPlan(Dims box) : box_(box) {
     // strided y and z passes camp on a few HBM channels (measured: z-conv 5 % slower at pitch 256 than at 272).
     pitch_ = xs_ + kW;
     col0_.alloc((size_t)box.ny * box.nz);
+#ifdef MIL_FX_EXPERIMENTS  // timing-only ablations (results invalid); compiled out of the product library
     ablate_ = env_int("MIL_FX_ABLATE", 0);
+#endif
     upload(tw_x_, twiddles(nx));
     upload(tw_y_, twiddles(ny));
     upload(tw_z_, twiddles(nz));

@@ -63,7 +63,7 @@ private:
     int xs_ = 0;     // spectral columns (multiple of 16)
     int pitch_ = 0;  // row pitch of a spectrum in complex elements (xs_ + 16)
     mutable DeviceBuffer<float2> col0_;  // [z][ky] copy of the packed column, forward y pass -> z kernels
-    int ablate_ = 0;   // MIL_FX_ABLATE: timing experiments only, results are wrong when non-zero
+    int ablate_ = 0;   // timing experiments only (build with -DMIL_FX_EXPERIMENTS, then MIL_FX_ABLATE); always 0 otherwise
     DeviceBuffer<float2> tw_x_, tw_y_, tw_z_;   // exp(-2*pi*i*k/n), k in [0, n)
     DeviceBuffer<unsigned short> pos_x_;        // position of element n after digit reversal, n in [0, nx/2)
     DeviceBuffer<unsigned short> freq_y_, freq_z_;  // frequency held at scrambled position p
