@@ -1,11 +1,12 @@
 // LDS-tiled 3-D real FFT / fused convolution kernels for gfx950 (see fftconv.h).
 //
-// Every kernel works on a tile of N x 16 complex64 held in LDS as float2 tile[N][17]
-// (the +1 column of padding keeps both the row-wise staging and the column-wise
-// butterflies at <= 2-way bank conflicts).  A 16-complex tile row is one 128-byte line
-// of HBM: 8 lanes x float4, so a wave moves 8 lines per instruction.
+// The column kernels (y pass, z convolution) work on a tile of N x 16 complex64 held in LDS as
+// float2 tile[N][17] (the +1 column of padding keeps both the row-wise staging and the column-wise
+// butterflies at <= 2-way bank conflicts; for the packed DC/Nyquist column it also carries the
+// Hermitian partner column).  A 16-complex tile row is one 128-byte line of HBM: 8 lanes x float4,
+// so a wave moves 8 lines per instruction.  The x kernel holds 8 volume rows as tile[nx/2][9].
 //
-// Transforms are in-place mixed-radix (8,8,..,{2,4}) Cooley-Tukey:
+// Transforms are in-place mixed-radix Cooley-Tukey (radix 8 first, then 4 / 2, then 3, 5, 7, 11, 13):
 //   DIF  natural order in  -> digit-reversed out   (forward y / z, inverse x)
 //   DIT  digit-reversed in -> natural order out    (inverse y / z, forward x)
 // DIT is the exact transpose of DIF, so forward-DIF followed by inverse-DIT needs no
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// x pass: 16 rows per workgroup, tile[k][row], packed real <-> complex
+// x pass: RB (= 8) volume rows per workgroup, tile[k][row], packed real <-> complex
 // ---------------------------------------------------------------------------
 struct XArgs {
     float2 *S;
