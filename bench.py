@@ -83,8 +83,14 @@ def cpu_baseline(img_host, psf_host, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 100 steps ~ 0.1 s of GPU time: the fixed cost of a run_single call (first pass over cold caches, clock ramp after the
+    # fence, ~1.3 ms) is then ~1 % of the timed region; at 20 steps it is 6 % (measured: 915 vs 980 it/s).
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    # The GPU raises its clock over the first ~50 ms of sustained load (measured: the marginal step costs 1.13 ms in the
+    # first 5 steps after idle, 1.02 ms after 50, 1.01 ms after 100).  A fixed number of untimed steps before the W
+    # warm-up steps brings it to the sustained state a long deconvolution runs in, whatever W the caller picks.
+    ap.add_argument("--clock-warm-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4)
@@ -130,18 +136,21 @@ def main():
     A = img_a.clone()
     E = torch.empty_like(A)
     eng.init_single(A, E)
-    eng.run_single(E, A, otf_a, bp_a, args.warmup)
+    eng.run_single(E, A, otf_a, bp_a, args.clock_warm_steps)  # untimed: clock ramp
+    eng.run_single(E, A, otf_a, bp_a, args.warmup)            # untimed: the W warm-up steps
     eng.sync()
 
     ALL_TIMERS = (mdev.DeconEngine.TIMER_UPDATE, mdev.DeconEngine.TIMER_RATIO, mdev.DeconEngine.TIMER_CMUL,
                   mdev.DeconEngine.TIMER_FFT)
     # Inside the timed region only the roofline kernel is bracketed with HIP events on the engine's stream
     # (fused backend: the y pass, 4 launches per step and the largest share of it; rocFFT backend: the OTF
-    # product).  Every event is a stream marker, so bracketing all 8 launches of a step would itself cost
-    # a few percent of it; the other families are timed in a second, un-clocked pass of the same K steps.
+    # product), and only every 4th launch of it (one per step).  An event pair is a pair of stream markers: the
+    # rocprofv3 trace shows 0 us between back-to-back kernels and 6-10 us across a marker, so bracketing all 8
+    # launches of a step would cost several percent of it.  The other families are timed in a second,
+    # un-clocked pass of the same K steps.
     dom_timer = mdev.DeconEngine.TIMER_FFT if fused else mdev.DeconEngine.TIMER_CMUL
     if not os.environ.get("MIL_BENCH_NO_EVENTS"):  # diagnostic: how much the in-region markers cost
-        eng.timer_enable(dom_timer, True)
+        eng.timer_enable(dom_timer, 4 if fused else 2)
 
     def fence():
         torch.cuda.synchronize()

@@ -83,6 +83,7 @@ int mil_decon_sync(mil_decon *e);
 /* HIP-event timers bracketing kernel families on the engine's stream.
  * which (ROCFFT backend): 0 rl_update, 1 rl_ratio, 2 cmul, 3 rocFFT executes;
  * which (FUSED backend):  0 x pass + estimate update, 1 x pass + ratio, 2 z convolution, 3 y passes. */
+/* enable: 0 off | 1 bracket every launch | n > 1 bracket every n-th launch (an event pair costs stream time) */
 int mil_decon_timer_enable(mil_decon *e, int which, int enable);
 int mil_decon_timer_read(mil_decon *e, int which, double *total_ms, size_t *launches); /* syncs, then resets */
 

@@ -163,6 +163,7 @@ int mil_decon_sync(mil_decon *e) {
 int mil_decon_timer_enable(mil_decon *e, int which, int enable) {
     if (which < 0 || which >= DeconEngine::kTimedCount) return -1;
     e->engine.timers[which].enabled = enable != 0;
+    e->engine.timers[which].every = enable > 1 ? enable : 1;  // enable = n > 1: bracket every n-th launch only
     e->engine.timers[which].reset();
     return 0;
 }

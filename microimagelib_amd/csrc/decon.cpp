@@ -85,6 +85,8 @@ void Fft3D::c2r(float2 *in, float *out) {
 // ---------------------------------------------------------------------------
 void KernelTimer::begin(hipStream_t s) {
     if (!enabled) return;
+    active = (seen++ % (every > 0 ? every : 1)) == 0;
+    if (!active) return;
     if (used + 2 > ev.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
@@ -96,7 +98,7 @@ void KernelTimer::begin(hipStream_t s) {
 }
 
 void KernelTimer::end(hipStream_t s) {
-    if (!enabled) return;
+    if (!enabled || !active) return;
     MIL_HIP(hipEventRecord(ev[used + 1], s));
     used += 2;
 }

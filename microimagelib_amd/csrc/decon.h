@@ -41,13 +41,16 @@ private:
 
 struct KernelTimer {  // HIP-event bracket around one kernel family, on the engine's stream
     bool enabled = false;
+    int every = 1;        // bracket every n-th launch of the family only (an event pair costs a few us of stream time)
+    int seen = 0;         // launches seen since enable
+    bool active = false;  // the current launch is bracketed
     std::vector<hipEvent_t> ev;  // start/stop pairs
     size_t used = 0;
     void begin(hipStream_t s);
     void end(hipStream_t s);
     // sums elapsed over recorded pairs; stream must be idle. Returns count.
     size_t collect(double *total_ms);
-    void reset() { used = 0; }
+    void reset() { used = 0; seen = 0; active = false; }
     ~KernelTimer();
 };
 

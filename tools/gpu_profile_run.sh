@@ -8,8 +8,8 @@ export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" > $out/tests.log
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-extra --backend rocfft > $out/bench_rocfft_backend.json 2> $out/bench_rocfft.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $out/prof_stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > $out/prof_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > $out/prof_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 20 --warmup 3 --clock-warm-steps 0 --no-cpu-baseline --no-extra > $out/prof_stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --steps 5 --warmup 1 --clock-warm-steps 0 --no-cpu-baseline --no-extra > $out/prof_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --steps 5 --warmup 1 --clock-warm-steps 0 --no-cpu-baseline --no-extra > $out/prof_write.log 2>&1
 find $out -size +20M -delete
 cat $out/tests.log $out/bench.json
