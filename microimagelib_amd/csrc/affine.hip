@@ -21,6 +21,8 @@
 // bookkeeping add more VALU work than the gathers they remove.  They live in the git history only.
 #include "kernels.h"
 
+#include <cstdlib>
+
 
 namespace mil {
 namespace k {
@@ -101,6 +103,42 @@ __device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int
     return Z.w0 * c0 + Z.w1 * c1;
 }
 
+// Plane cache of the cost kernel.  A lane walks z; for the near-axis-aligned matrices registration visits, the lower
+// source plane of step z+1 is the upper plane of step z (same row pair, same x pair), so its two 8-byte gathers were
+// already fetched.  Reuse is decided by ADDRESS equality -- it never changes a value, only skips a gather -- and cuts
+// the gathers per voxel from 4 to ~2 (the kernel is bound by gather issue).
+struct PlaneCache {
+    size_t a0 = ~(size_t)0, a1 = ~(size_t)0;  // element offsets of the cached upper-plane pairs (rows y0, y1)
+    Pair q0{0.f, 0.f}, q1{0.f, 0.f};
+};
+
+__device__ __forceinline__ float fetch_linear_cached(const float *__restrict__ src, int sx, int sy, int sz, float tx,
+                                                     float ty, float tz, PlaneCache &pc) {
+    Tap X = make_tap(tx, sx), Y = make_tap(ty, sy), Z = make_tap(tz, sz);
+    const size_t row = (size_t)sx, plane = (size_t)sx * sy;
+    const int b = X.i0 < sx - 2 ? X.i0 : sx - 2;  // sx >= 2 guaranteed by the launcher
+    const bool lo0 = X.i0 == b, lo1 = X.i1 == b;
+    const size_t o00 = Z.i0 * plane + Y.i0 * row + b, o01 = Z.i0 * plane + Y.i1 * row + b;
+    const size_t o10 = Z.i1 * plane + Y.i0 * row + b, o11 = Z.i1 * plane + Y.i1 * row + b;
+    Pair q00, q01;
+    if (o00 == pc.a0 && o01 == pc.a1) {
+        q00 = pc.q0;
+        q01 = pc.q1;
+    } else {
+        q00 = *reinterpret_cast<const Pair *>(src + o00);
+        q01 = *reinterpret_cast<const Pair *>(src + o01);
+    }
+    const Pair q10 = *reinterpret_cast<const Pair *>(src + o10), q11 = *reinterpret_cast<const Pair *>(src + o11);
+    pc.a0 = o10; pc.a1 = o11; pc.q0 = q10; pc.q1 = q11;
+    float c00 = X.w0 * (lo0 ? q00.lo : q00.hi) + X.w1 * (lo1 ? q00.lo : q00.hi);
+    float c01 = X.w0 * (lo0 ? q01.lo : q01.hi) + X.w1 * (lo1 ? q01.lo : q01.hi);
+    float c10 = X.w0 * (lo0 ? q10.lo : q10.hi) + X.w1 * (lo1 ? q10.lo : q10.hi);
+    float c11 = X.w0 * (lo0 ? q11.lo : q11.hi) + X.w1 * (lo1 ? q11.lo : q11.hi);
+    float c0 = Y.w0 * c00 + Y.w1 * c01;
+    float c1 = Y.w0 * c10 + Y.w1 * c11;
+    return Z.w0 * c0 + Z.w1 * c1;
+}
+
 // affinetransformkernel, reference include/cukernel.cuh:501-524 (window 0 <= t < s2).
 // STRICT: the 2-D variant tests 0 < t (affineTransform2Dkernel, include/cukernel.cuh:558-573).
 template <bool STRICT>
@@ -134,7 +172,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 //
 // FLOAT_PRODUCTS: the 2-D variant of the reference (corr2Dkernel, include/cukernel.cuh:575-597) forms t*t and s*t in
 // float32 and sums those in float64 on the host (src/api_subfunc.cu:1027-1030); a 2-D image is a one-plane volume here.
-template <bool FLOAT_PRODUCTS>
+// CACHE: reuse the previous step's upper source plane when it is this step's lower one (needs sx >= 2).
+template <bool FLOAT_PRODUCTS, bool CACHE>
 __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__restrict__ tgt,
                                                            const float *__restrict__ src, AffineArgs a,
                                                            double *__restrict__ partials, int nblocks) {
@@ -149,6 +188,7 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
         const int z1 = (z0 + kCorrZ < a.tz) ? z0 + kCorrZ : a.tz;
         const float *tp = tgt + (size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z0);
         const size_t tstep = (size_t)a.tx * a.ty;
+        PlaneCache pc;
 #pragma unroll 4
         for (int z = z0; z < z1; ++z, tp += tstep) {
             const float iz = (float)z;
@@ -157,7 +197,8 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
             const float tz = coord(a.m + 8, ix, iy, iz);
             float sv = 0.0f;
             if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
-                sv = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
+                sv = CACHE ? fetch_linear_cached(src, a.sx, a.sy, a.sz, tx, ty, tz, pc)
+                           : fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
             const float tv = *tp;
             if (FLOAT_PRODUCTS) {
                 const float q = sv * sv, c = tv * sv;
@@ -256,12 +297,16 @@ void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
     if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
-    if (float_products)
-        hipLaunchKernelGGL(corr_kernel<true>, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
+    static const bool no_cache = getenv("MIL_CORR_NOCACHE") && getenv("MIL_CORR_NOCACHE")[0] == '1';
+    if (float_products)  // 2-D images (one plane): nothing to reuse along z
+        hipLaunchKernelGGL((corr_kernel<true, false>), grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
+                           (int)nblocks);
+    else if (a.sx >= 2 && !no_cache)
+        hipLaunchKernelGGL((corr_kernel<false, true>), grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
                            (int)nblocks);
     else
-        hipLaunchKernelGGL(corr_kernel<false>, grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
-                           (int)nblocks);
+        hipLaunchKernelGGL((corr_kernel<false, false>), grid, dim3(kBlockThreads), 0, s, target, src, a,
+                           ws.partials.get(), (int)nblocks);
     MIL_HIP(hipGetLastError());
     // the final pass writes (ss, st) straight into pinned host memory: no copy node, one stream sync per evaluation
     hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(kFinalThreads), 0, s, ws.partials.get(), (int)nblocks, ws.host);
