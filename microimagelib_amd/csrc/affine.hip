@@ -12,8 +12,8 @@
 // Per target voxel: one coalesced target read and four 8-byte source gathers whose footprint,
 // for the near-identity matrices registration visits, is a sheared box only slightly larger
 // than the target tile -- the gathers hit L1/L2 and HBM traffic stays ~ (target + source) bytes.
-// Measured limits (rocprofv3 PMC at 512x512x256, profiles/r01_final/reg_cost_kernel.json): the cost kernel issues 104
-// VALU and 5 vector-memory instructions per voxel-wave; the texture-address path is busy 73 % of the time (a quad of lanes
+// Measured limits (rocprofv3 PMC at 512x512x256, profiles/r01_final/reg_cost_kernel.json): before the plane cache the
+// cost kernel issued 104 VALU and 5 vector-memory instructions per voxel-wave; the texture-address path was busy 73 % (a quad of lanes
 // per cycle) and VALU issue ~50 %, so it is co-limited by gather issue and arithmetic, not by HBM
 // (29 % of the 2R roofline).  Two LDS-staged variants (a 32x16x16 slab with an exact bounding box,
 // and a z-marching ring of source planes with an 8-deep register prefetch FIFO) were built and
