@@ -94,6 +94,16 @@ int mil_affine_resample(float *d_out, const float *d_src, int ox, int oy, int oz
 /* corrkernel + 2x sumgpu1D, include/cukernel.cuh:526, src/api_subfunc.cu:954-988: h_out = {sum s*s, sum s*t} */
 int mil_corr_sums(const float *d_target, const float *d_src, int tx, int ty, int tz, int sx, int sy, int sz,
                   const float *m12, double *h_out, void *stream);
+/* The same two sums with the source held as a copy with a replicated one-voxel border ([sz+2][sy+2][sx+2]: the
+ * texture unit's clamp addressing materialised in memory) -- the form mil_reg3d_affine evaluates ~10^3 times per
+ * registration.  Bit-identical to mil_corr_sums.  create fails (-1) when the volumes are beyond the kernel's 32-bit
+ * offset range (mil_padded_source_eligible == 0); the caller then stays with mil_corr_sums. */
+typedef struct mil_padded_source mil_padded_source;
+int mil_padded_source_eligible(int tx, int ty, int tz, int sx, int sy, int sz);
+int mil_padded_source_create(mil_padded_source **out, const float *d_src, int sx, int sy, int sz, void *stream);
+void mil_padded_source_destroy(mil_padded_source *p);
+int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, int tx, int ty, int tz,
+                         const float *m12, double *h_out, void *stream);
 /* reg3d_affine1, src/api_subfunc.cu:2733-2994, on device-resident volumes of equal size */
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records,

@@ -83,6 +83,10 @@ SIGNATURES = {
     "mil_decon_timer_read": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
     "mil_affine_resample": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, C.c_void_p]),
     "mil_corr_sums": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, c_double_p, C.c_void_p]),
+    "mil_padded_source_eligible": (C.c_int, [C.c_int] * 6),
+    "mil_padded_source_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
+    "mil_padded_source_destroy": (None, [C.c_void_p]),
+    "mil_corr_sums_padded": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [c_float_p, c_double_p, C.c_void_p]),
     "mil_reg3d_affine": (C.c_int, [C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, C.c_void_p]),
     "mil_reg3d_mip_shift": (C.c_int, [c_float_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -309,6 +309,10 @@ void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_
                            ws.partials.get(), (int)nblocks);
     MIL_HIP(hipGetLastError());
     // the final pass writes (ss, st) straight into pinned host memory: no copy node, one stream sync per evaluation
+    corr_final_launch(ws, nblocks, s);
+}
+
+void corr_final_launch(CorrWorkspace &ws, size_t nblocks, hipStream_t s) {
     hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(kFinalThreads), 0, s, ws.partials.get(), (int)nblocks, ws.host);
     MIL_HIP(hipGetLastError());
 }

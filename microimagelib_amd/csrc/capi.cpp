@@ -202,6 +202,40 @@ int mil_corr_sums(const float *d_target, const float *d_src, int tx, int ty, int
         return 0;
     });
 }
+struct mil_padded_source {
+    k::PaddedSource src;
+};
+int mil_padded_source_eligible(int tx, int ty, int tz, int sx, int sy, int sz) {
+    return k::PaddedSource::eligible(dims3(tx, ty, tz), dims3(sx, sy, sz)) ? 1 : 0;
+}
+int mil_padded_source_create(mil_padded_source **out, const float *d_src, int sx, int sy, int sz, void *stream) {
+    return guarded("mil_padded_source_create", [&] {
+        if (!out || !d_src) throw Error(-1, "mil_padded_source_create: null argument");
+        *out = nullptr;
+        if (!k::PaddedSource::eligible(dims3(sx, sy, sz), dims3(sx, sy, sz)))
+            throw Error(-1, "mil_padded_source_create: volume beyond the padded kernel's 32-bit offset range");
+        std::unique_ptr<mil_padded_source> p(new mil_padded_source());
+        p->src.build(d_src, dims3(sx, sy, sz), as_stream(stream));
+        *out = p.release();
+        return 0;
+    });
+}
+void mil_padded_source_destroy(mil_padded_source *p) { delete p; }
+int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, int tx, int ty, int tz,
+                         const float *m12, double *h_out, void *stream) {
+    return guarded("mil_corr_sums_padded", [&] {
+        if (!src) throw Error(-1, "mil_corr_sums_padded: null source");
+        k::Affine12 m;
+        std::memcpy(m.m, m12, sizeof m.m);
+        static thread_local std::map<int, std::unique_ptr<k::CorrWorkspace>> cache;
+        int dev = 0;
+        MIL_HIP(hipGetDevice(&dev));
+        auto &ws = cache[dev];
+        if (!ws) ws.reset(new k::CorrWorkspace());
+        k::corr_sums_padded_sync(d_target, src->src, dims3(tx, ty, tz), m, *ws, as_stream(stream), &h_out[0], &h_out[1]);
+        return 0;
+    });
+}
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records, void *stream) {
     return guarded("mil_reg3d_affine", [&] {

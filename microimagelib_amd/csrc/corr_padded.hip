@@ -1,0 +1,234 @@
+// Registration cost kernel on a border-padded source: the hottest kernel of a time-lapse batch (a 12-DOF Powell
+// cascade evaluates it ~2 300 times per volume pair).
+//
+// The 3-D registration keeps its mean-subtracted source with a one-voxel REPLICATED border on every side,
+// [sz+2][sy+2][sx+2].  The border is the texture unit's clamp addressing (reference include/cukernel.cuh:526-556 reads
+// a clamped, linearly filtered 3-D texture) materialised in memory: a tap at index -1 or n reads the replicated edge
+// voxel.  Inside the validity window floor(t - 0.5) lies in [-1, n-1] and indexes the padded volume directly, so
+//   * there are no index clamps and no edge selects;
+//   * the four 8-byte gathers of a voxel share ONE 32-bit byte offset: they go through a buffer descriptor whose
+//     scalar offset carries the row / plane pitch;
+//   * that offset is two 24-bit multiplies and two adds instead of 64-bit multiply-adds.
+// The float32 operations and their order are those of fetch_linear (affine.hip), so the two sums are bit-identical to
+// corr_kernel's on the unpadded volume.  The kernel is VALU-issue bound, so the arithmetic is written in explicit
+// 2-wide vectors (v_pk_mul_f32 / v_pk_add_f32) and this file is compiled with the SLP vectoriser off -- left on, it
+// turns the six window compares into a bit-mask reduction that costs more than it saves.
+#include "kernels.h"
+
+namespace mil {
+namespace k {
+
+namespace {
+
+constexpr int kTileX = 64;  // one wave = 64 consecutive x: coalesced target reads
+constexpr int kTileY = 4;   // waves per workgroup
+constexpr int kStepsZ = 16; // z steps per lane
+constexpr int kThreads = kTileX * kTileY;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct PaddedArgs {
+    float m[12];
+    int tx, ty, tz;       // target extents
+    float sxf, syf, szf;  // source extents: the validity window 0 < t < s
+    int row4;             // padded row pitch in bytes, 4 * (sx + 2)
+    int plane4;           // padded plane pitch in bytes
+    int origin4;          // byte offset of source voxel (0, 0, 0) inside the padded volume
+    unsigned bytes;       // size of the padded volume
+};
+
+// (lo, hi) = two adjacent source voxels; address = base + voffset (per lane) + soffset (uniform)
+__device__ __forceinline__ f32x2 gather_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, (int)soffset, 0);
+    return __builtin_bit_cast(f32x2, v);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__restrict__ tgt,
+                                                             const float *__restrict__ srcp, PaddedArgs a,
+                                                             double *__restrict__ partials, int nblocks) {
+    __shared__ double lds[2 * kTileY];
+    const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
+    const int x = blockIdx.x * kTileX + lane;
+    const int y = blockIdx.y * kTileY + wave;
+    const int z0 = blockIdx.z * kStepsZ;
+    double ss = 0.0, st = 0.0;
+    if (x < a.tx && y < a.ty) {
+        const float ix = (float)x, iy = (float)y;
+        const int z1 = (z0 + kStepsZ < a.tz) ? z0 + kStepsZ : a.tz;
+        // t = ((m0*x + m1*y) + m2*z) + m3, then + 0.5: the reference's left-to-right float32 evaluation; the x / y
+        // part does not change along z
+        const f32x2 mxy0 = {a.m[0], a.m[4]}, mxy1 = {a.m[1], a.m[5]}, mxy2 = {a.m[2], a.m[6]}, mxy3 = {a.m[3], a.m[7]};
+        const f32x2 hxy = mxy0 * ix + mxy1 * iy;
+        const float hz = a.m[8] * ix + a.m[9] * iy;
+        const f32x2 half2 = {0.5f, 0.5f};
+        // gfx950 raw buffer: dword 3 = 0x00020000 (32-bit data format), records = bytes
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(srcp), 0, (int)a.bytes, 0x00020000);
+        const unsigned s01 = (unsigned)a.row4, s10 = (unsigned)a.plane4, s11 = (unsigned)(a.plane4 + a.row4);
+        const char *tbase = reinterpret_cast<const char *>(tgt);
+        unsigned toff = 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)y + (unsigned)a.ty * (unsigned)z0));
+        const unsigned tstep = 4u * (unsigned)a.tx * (unsigned)a.ty;
+        // One z step of one lane: weights, the byte offset of its lower-plane row pair, window flag, target value.
+        struct Step {
+            f32x2 wx, wy, wz;  // (1 - w, w) per axis
+            unsigned off;
+            bool in;
+            float tv;
+        };
+        auto prepare = [&](int z, unsigned toff) {
+            Step p;
+            const float iz = (float)z;
+            const f32x2 txy = ((hxy + mxy2 * iz) + mxy3) + half2;
+            const float tz = ((hz + a.m[10] * iz) + a.m[11]) + 0.5f;
+            const bool gx = txy.x > 0, lx = txy.x < a.sxf, gy = txy.y > 0, ly = txy.y < a.syf, gz = tz > 0, lz = tz < a.szf;
+            p.in = gx && lx && gy && ly && gz && lz;
+            const f32x2 bxy = txy - half2;
+            const float bz = tz - 0.5f;
+            const float fx = floorf(bxy.x), fy = floorf(bxy.y), fz = floorf(bz);
+            p.wx.y = bxy.x - fx;
+            p.wx.x = 1.0f - p.wx.y;
+            p.wy.y = bxy.y - fy;
+            p.wy.x = 1.0f - p.wy.y;
+            p.wz.y = bz - fz;
+            p.wz.x = 1.0f - p.wz.y;
+            // in the window every index lies in [-1, n-1]; outside, the offset is replaced by a valid one and the
+            // value discarded, so no lane ever leaves the padded volume
+            const unsigned off = (unsigned)(__mul24((int)fz, a.plane4) + __mul24((int)fy, a.row4) + a.origin4) +
+                                 ((unsigned)(int)fx << 2);
+            p.off = p.in ? off : 0u;
+            p.tv = *reinterpret_cast<const float *>(tbase + toff);
+            return p;
+        };
+        // lo = rows (y0, y1) of the lower source plane, up = of the upper one; the reference's interpolation order
+        auto accumulate = [&](const Step &p, f32x2 lo0, f32x2 lo1, f32x2 up0, f32x2 up1) {
+            const f32x2 p00 = p.wx * lo0, p01 = p.wx * lo1, p10 = p.wx * up0, p11 = p.wx * up1;
+            const f32x2 lower = {p00.x + p00.y, p01.x + p01.y}, upper = {p10.x + p10.y, p11.x + p11.y};
+            const f32x2 el = p.wy * lower, eu = p.wy * upper;
+            const f32x2 e = {el.x + el.y, eu.x + eu.y};
+            const f32x2 rz = p.wz * e;
+            const float r = rz.x + rz.y;
+            const float sv = __uint_as_float(p.in ? __float_as_uint(r) : 0u);
+            // float x float is exact in double, so the fused form rounds exactly like multiply-then-add
+            ss = __builtin_fma((double)sv, (double)sv, ss);
+            st = __builtin_fma((double)sv, (double)p.tv, st);
+        };
+        // Software pipeline, one step deep: the gathers of step z are in flight while step z-1 is interpolated.
+        // Plane reuse: when a lane moved exactly one source plane (same row pair, same x pair -- decided by offset
+        // equality, so it can only skip a gather, never change a value) the upper plane of step z-1 is the lower
+        // plane of step z; only the other lanes gather it.  ~2 instead of 4 gathers per voxel for the
+        // near-axis-aligned matrices registration visits.
+        Step cur = prepare(z0, toff);
+        f32x2 lo0 = gather_pair(rsrc, cur.off, 0u), lo1 = gather_pair(rsrc, cur.off, s01);
+        f32x2 up0 = gather_pair(rsrc, cur.off, s10), up1 = gather_pair(rsrc, cur.off, s11);
+#pragma unroll 4
+        for (int z = z0 + 1; z < z1; ++z) {
+            toff += tstep;
+            const Step nxt = prepare(z, toff);
+            const f32x2 n0 = gather_pair(rsrc, nxt.off, s10), n1 = gather_pair(rsrc, nxt.off, s11);
+            accumulate(cur, lo0, lo1, up0, up1);
+            if (nxt.off != cur.off + (unsigned)a.plane4) {
+                lo0 = gather_pair(rsrc, nxt.off, 0u);
+                lo1 = gather_pair(rsrc, nxt.off, s01);
+            } else {
+                lo0 = up0;
+                lo1 = up1;
+            }
+            up0 = n0;
+            up1 = n1;
+            cur = nxt;
+        }
+        accumulate(cur, lo0, lo1, up0, up1);
+    }
+    ss = wave_sum(ss);
+    st = wave_sum(st);
+    if (lane == 0) {
+        lds[wave] = ss;
+        lds[kTileY + wave] = st;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTileY; ++w) {
+            a0 += lds[w];
+            a1 += lds[kTileY + w];
+        }
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        partials[b] = a0;
+        partials[nblocks + b] = a1;
+    }
+}
+
+// dst[z+1][y+1][x+1] = src[z][y][x]; border voxels replicate the nearest edge voxel.
+__global__ __launch_bounds__(256) void pad_replicate_kernel(float *__restrict__ dst, const float *__restrict__ src,
+                                                          int sx, int sy, int sz) {
+    const int xp = blockIdx.x * 256 + threadIdx.x, yp = blockIdx.y, zp = blockIdx.z;
+    if (xp >= sx + 2) return;
+    const int x = min(max(xp - 1, 0), sx - 1), y = min(max(yp - 1, 0), sy - 1), z = min(max(zp - 1, 0), sz - 1);
+    dst[(size_t)xp + (size_t)(sx + 2) * ((size_t)yp + (size_t)(sy + 2) * zp)] =
+        src[(size_t)x + (size_t)sx * ((size_t)y + (size_t)sy * z)];
+}
+
+}  // namespace
+
+bool PaddedSource::eligible(Dims t, Dims s) {
+    if (t.nx <= 0 || t.ny <= 0 || t.nz <= 0 || s.nx <= 0 || s.ny <= 0 || s.nz <= 0) return false;
+    const long long xp = s.nx + 2, yp = s.ny + 2, zp = s.nz + 2;
+    // every byte offset fits 32 bits (the buffer's record count is a signed int: 2 GiB); both operands of each 24-bit
+    // multiply fit 23 bits + sign; float32 holds every target index exactly
+    return xp * yp * zp * 4 < (1ll << 31) && t.count() * 4 < (1ll << 32) && xp * yp * 4 < (1ll << 23) &&
+           zp < (1ll << 23) && t.nx <= (1 << 24) && t.ny <= (1 << 24) && t.nz <= (1 << 24);
+}
+
+void PaddedSource::build(const float *src, Dims d, hipStream_t s) {
+    if (d.nx <= 0 || d.ny <= 0 || d.nz <= 0) throw Error(-1, "PaddedSource: empty volume");
+    if (d.ny + 2 > 65535 || d.nz + 2 > 65535) throw Error(-1, "PaddedSource: volume exceeds launch limits");
+    dims = d;
+    const size_t n = (size_t)(d.nx + 2) * (d.ny + 2) * (d.nz + 2);
+    if (data.size() < n) data.alloc(n);
+    dim3 grid((unsigned)div_up(d.nx + 2, 256), (unsigned)(d.ny + 2), (unsigned)(d.nz + 2));
+    hipLaunchKernelGGL(pad_replicate_kernel, grid, dim3(256), 0, s, data.get(), src, (int)d.nx, (int)d.ny, (int)d.nz);
+    MIL_HIP(hipGetLastError());
+}
+
+void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
+                            hipStream_t s) {
+    if (!PaddedSource::eligible(t, src.dims) || !src.data.get())
+        throw Error(-1, "corr_sums_padded: volume outside the 32-bit offset range");
+    PaddedArgs a;
+    for (int i = 0; i < 12; ++i) a.m[i] = m.m[i];
+    a.tx = (int)t.nx; a.ty = (int)t.ny; a.tz = (int)t.nz;
+    a.sxf = (float)src.dims.nx; a.syf = (float)src.dims.ny; a.szf = (float)src.dims.nz;
+    const long long xp = src.dims.nx + 2, yp = src.dims.ny + 2;
+    a.row4 = (int)(4 * xp);
+    a.plane4 = (int)(4 * xp * yp);
+    a.origin4 = (int)(4 * (xp * yp + xp + 1));
+    a.bytes = (unsigned)(4 * xp * yp * (src.dims.nz + 2));
+    dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kStepsZ - 1) / kStepsZ);
+    if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
+    if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
+    hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, ws.partials.get(),
+                       (int)nblocks);
+    MIL_HIP(hipGetLastError());
+    corr_final_launch(ws, nblocks, s);
+}
+
+void corr_sums_padded_sync(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
+                           hipStream_t s, double *ss, double *st) {
+    corr_sums_padded_async(target, src, t, m, ws, s);
+    MIL_HIP(hipStreamSynchronize(s));
+    *ss = ws.host[0];
+    *st = ws.host[1];
+}
+
+}  // namespace k
+}  // namespace mil

@@ -95,5 +95,22 @@ void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_
 void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
                     CorrWorkspace &ws, hipStream_t s, double *ss, double *st, bool float_products = false);
 
+
+// Source volume with a one-voxel replicated border, [sz+2][sy+2][sx+2]: the border stands in for the texture unit's
+// clamp addressing, so the cost kernel needs neither index clamps nor edge selects (affine.hip).  Same sums, bit for
+// bit, as corr_sums_* on the unpadded volume.
+struct PaddedSource {
+    DeviceBuffer<float> data;
+    Dims dims{0, 0, 0};  // unpadded extents
+    static bool eligible(Dims target, Dims source);  // all byte offsets fit 32 bits
+    void build(const float *src, Dims dims, hipStream_t s);
+};
+// second stage of every cost evaluation: sums the per-workgroup partials into ws.host (pinned)
+void corr_final_launch(CorrWorkspace &ws, size_t nblocks, hipStream_t s);
+void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t_dims, const Affine12 &m,
+                            CorrWorkspace &ws, hipStream_t s);
+void corr_sums_padded_sync(const float *target, const PaddedSource &src, Dims t_dims, const Affine12 &m,
+                           CorrWorkspace &ws, hipStream_t s, double *ss, double *st);
+
 }  // namespace k
 }  // namespace mil

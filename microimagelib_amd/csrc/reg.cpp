@@ -2,6 +2,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include <vector>
@@ -437,6 +438,15 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
     const float sd_t = (float)std::sqrt(sqr1);
     if (sd_t == 0.f) throw Error(-3, "reg3d_affine: SD of image 1 is zero (empty image)");
 
+    // The cost kernel reads the source through a copy with a replicated one-voxel border (corr_padded.hip); volumes
+    // beyond its 32-bit offset range keep the general kernel.  Same sums either way.
+    k::PaddedSource src_pad;
+    const bool padded = k::PaddedSource::eligible(dims, dims) && !(getenv("MIL_CORR_UNPADDED") && getenv("MIL_CORR_UNPADDED")[0] == '1');
+    if (padded) {
+        src_pad.build(src_ms.get(), dims, stream);
+        src_ms.release();
+    }
+
     int evals = 0;
     bool dof9 = false;
     int dof_num = 12;
@@ -444,7 +454,8 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
         if (dof9) dof9tomatrix(aff.m, x, dof_num);
         else p2matrix(aff.m, x);
         double ss = 0, st = 0;
-        k::corr_sums_sync(tgt_ms.get(), src_ms.get(), dims, dims, aff, corr, stream, &ss, &st);
+        if (padded) k::corr_sums_padded_sync(tgt_ms.get(), src_pad, dims, aff, corr, stream, &ss, &st);
+        else k::corr_sums_sync(tgt_ms.get(), src_ms.get(), dims, dims, aff, corr, stream, &ss, &st);
         ++evals;
         const double root = std::sqrt(ss);
         const float zncc = (root == 0) ? -2.0f : (float)(st / root) / sd_t;

@@ -113,9 +113,42 @@ def affine_resample(src: torch.Tensor, m12, out_shape, stream=None):
     return out
 
 
-def corr_sums(target: torch.Tensor, src: torch.Tensor, m12, stream=None):
+class PaddedSource:
+    """Source volume copied with a replicated one-voxel border -- the form the registration cost kernel reads
+    (csrc/corr_padded.hip).  Pass it to corr_sums in place of the source tensor."""
+
+    def __init__(self, src: torch.Tensor, stream=None):
+        if src.dtype != torch.float32 or src.dim() != 3:
+            raise ValueError("expected a float32 volume [z][y][x]")
+        self.shape = tuple(src.shape)
+        self._h = C.c_void_p()
+        _check(_lib.load().mil_padded_source_create(C.byref(self._h), _ptr(src), *_dims(src), _stream_ptr(stream)),
+               "mil_padded_source_create")
+
+    @staticmethod
+    def eligible(target_shape, source_shape) -> bool:
+        t, s = tuple(target_shape), tuple(source_shape)
+        return bool(_lib.load().mil_padded_source_eligible(t[2], t[1], t[0], s[2], s[1], s[0]))
+
+    def close(self):
+        if self._h:
+            _lib.load().mil_padded_source_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def corr_sums(target: torch.Tensor, src, m12, stream=None):
     m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)
     out = (C.c_double * 2)()
+    if isinstance(src, PaddedSource):
+        _check(_lib.load().mil_corr_sums_padded(_ptr(target), src._h, *_dims(target), m.ctypes.data_as(_lib.c_float_p),
+                                                out, _stream_ptr(stream)), "mil_corr_sums_padded")
+        return out[0], out[1]
     _check(_lib.load().mil_corr_sums(_ptr(target), _ptr(src), *_dims(target), *_dims(src),
                                      m.ctypes.data_as(_lib.c_float_p), out, _stream_ptr(stream)), "mil_corr_sums")
     return out[0], out[1]

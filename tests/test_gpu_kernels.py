@@ -189,6 +189,60 @@ def test_affine_golden(dev):
     assert bits_equal(got, g["resized"])
 
 
+def _bits(v):
+    return np.float64(v).view(np.uint64)
+
+
+def test_padded_cost_kernel_is_bit_identical(dev):
+    """The registration's cost kernel reads the source through a border-padded copy (csrc/corr_padded.hip): same two
+    sums, bit for bit, as the general kernel -- golden matrices (texel centres, edges, all-out-of-window), random
+    affine matrices, and matrices that put many voxels on the replicated border."""
+    g = np.load(os.path.join(GOLD, "affine.npz"))
+    src, tgt = T(g["src"]), T(g["tgt"])
+    pad = dev.PaddedSource(src)
+    for i, m in enumerate(g["mats"]):
+        a, b = dev.corr_sums(tgt, src, m), dev.corr_sums(tgt, pad, m)
+        assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"golden matrix {i}"
+        want_ss, want_st = g["corr_sums"][i]
+        assert abs(b[0] - want_ss) <= 1e-12 * max(abs(want_ss), 1e-30)
+        assert abs(b[1] - want_st) <= 1e-11 * max(abs(want_ss), 1e-30)
+    pad.close()
+    rng = np.random.default_rng(7)
+    for shape_s, shape_t in (((17, 23, 70), (19, 21, 66)), ((5, 3, 2), (6, 4, 3)), ((1, 1, 1), (3, 3, 3)),
+                             ((33, 40, 130), (33, 40, 130))):
+        src = rng.standard_normal(shape_s).astype(f32)
+        tgt = rng.standard_normal(shape_t).astype(f32)
+        ds, dt = T(src), T(tgt)
+        pad = dev.PaddedSource(ds)
+        mats = []
+        for k in range(6):
+            m = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=f32) + rng.normal(0, 0.05 * k, 12).astype(f32)
+            m[[3, 7, 11]] = rng.uniform(-3, 3, 3).astype(f32)
+            mats.append(m)
+        ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=f32)
+        for d in (-0.5, -0.25, 0.25, 0.5, -1.0):  # half-voxel shifts: taps on the replicated border / exact centres
+            m = ident.copy()
+            m[[3, 7, 11]] = d
+            mats.append(m)
+        mats.append(ident * f32(0.0))                       # everything maps to t = 0.5
+        mats.append(np.full(12, 1e30, dtype=f32))           # overflows to inf / nan: all out of the window
+        mats.append(np.full(12, np.nan, dtype=f32))
+        for i, m in enumerate(mats):
+            a, b = dev.corr_sums(dt, ds, m), dev.corr_sums(dt, pad, m)
+            assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"{shape_s} matrix {i}"
+            if i < 11:
+                wss, wst = ro.corr_sums(tgt, src, m)
+                assert abs(b[0] - wss) <= 1e-12 * max(wss, 1e-30) and abs(b[1] - wst) <= 1e-11 * max(wss, 1e-30)
+        pad.close()
+
+
+def test_padded_source_eligibility(dev):
+    assert dev.PaddedSource.eligible((256, 512, 512), (256, 512, 512))
+    assert dev.PaddedSource.eligible((64, 1024, 1024), (64, 1024, 1024))
+    assert not dev.PaddedSource.eligible((64, 2048, 2048), (64, 2048, 2048))   # plane pitch beyond 2^23 bytes
+    assert not dev.PaddedSource.eligible((1024, 1024, 1024), (1024, 1024, 1024))  # beyond 2 GiB
+
+
 def test_affine_identity_is_exact_copy(dev):
     """Sample points are texel centres: the identity matrix reproduces the input."""
     import torch

@@ -277,6 +277,14 @@ def test_full_size_registration_properties(dev):
     ss, st = dev.corr_sums(ms, ms, ident)
     assert abs(st / ss - 1.0) < 1e-12 and ss > 0
     ss2, st2 = dev.corr_sums(ms * 2.0, ms, ident)  # linear in the target
+    pad = dev.PaddedSource(ms)  # the border-padded form reg3d evaluates: same bits at full size
+    rot = ident.copy()
+    c, s_ = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+    rot[[0, 2, 8, 10]] = np.array([c, -s_, s_, c], dtype=np.float32) * np.float32(1.02)
+    rot[[3, 7, 11]] = (7.0, -3.0, -11.0)
+    for m in (ident, rot):
+        assert dev.corr_sums(ms, pad, m) == dev.corr_sums(ms, ms, m)
+    pad.close()
     assert abs(ss2 - ss) <= 1e-12 * ss and abs(st2 - 2.0 * st) <= 1e-9 * abs(st)
     shift = ident.copy()
     shift[3], shift[7], shift[11] = 4.0, -3.0, 2.0

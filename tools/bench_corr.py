@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the registration cost kernel (mil_corr_sums) at 512x512x256."""
+"""Micro-benchmark of the registration cost kernels at 512x512x256: the border-padded form reg3d evaluates
+(mil_corr_sums_padded, default) or, with --general, the general kernel (mil_corr_sums)."""
 import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +11,9 @@ shape = (256, 512, 512)
 g = torch.Generator(device="cuda").manual_seed(0)
 tgt = torch.rand(shape, device="cuda", generator=g)
 src = torch.rand(shape, device="cuda", generator=g)
+general = "--general" in sys.argv
+source = src if general else mdev.PaddedSource(src)
+print("kernel:", "corr_kernel (general)" if general else "corr_padded_kernel")
 
 def matrix(deg, scale, shift):
     c, s = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
@@ -20,12 +24,12 @@ def matrix(deg, scale, shift):
 
 for name, m in (("identity", matrix(0, 1, (0, 0, 0))), ("rot3_s1.02", matrix(3, 1.02, (5, -3, 2))),
                 ("rot10", matrix(10, 1.0, (0, 0, 0))), ("rot45", matrix(45, 1.0, (0, 0, 0)))):
-    ss, st = mdev.corr_sums(tgt, src, m)
+    ss, st = mdev.corr_sums(tgt, source, m)
     torch.cuda.synchronize()
     n = 50
     t0 = time.perf_counter()
     for _ in range(n):
-        r = mdev.corr_sums(tgt, src, m)
+        r = mdev.corr_sums(tgt, source, m)
     dt = (time.perf_counter() - t0) / n
     vox = tgt.numel()
     print(f"{name:12s} {dt*1e3:8.3f} ms/eval  {vox/dt/1e9:8.1f} Gvoxel/s  {2*4*vox/dt/1e9:8.1f} GB/s algorithmic  ss={ss:.6e} st={st:.6e}")

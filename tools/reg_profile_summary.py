@@ -8,16 +8,20 @@ import collections, csv, glob, json, os, sys
 NAMES = ["identity", "rot3_scale1.02", "rot10", "rot45"]  # order and 51 launches each: tools/bench_corr.py
 
 
+def is_cost(name):
+    return "corr_kernel" in name or "corr_padded_kernel" in name
+
+
 def newest(pattern):
     files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     return files[-1] if files else None
 
 
 def main(src, dst):
-    out = {"command": "rocprofv3 ... -- python tools/bench_corr.py (4 matrices x 51 evaluations of mil_corr_sums at "
+    out = {"command": "rocprofv3 ... -- python tools/bench_corr.py (4 matrices x 51 evaluations of mil_corr_sums_padded at "
                       "512x512x256); counters = one launch of each matrix (the 11th)"}
     f = newest(os.path.join(src, "reg_stats", "**", "*_kernel_trace.csv"))
-    rows = [r for r in csv.DictReader(open(f)) if "corr_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if is_cost(r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     out["kernel_us_median"] = {n: sorted(d[i * 51:(i + 1) * 51])[25] for i, n in enumerate(NAMES)}
@@ -31,7 +35,7 @@ def main(src, dst):
             continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "corr_kernel" in r["Kernel_Name"]:
+            if is_cost(r["Kernel_Name"]):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             out["counters"][k] = {n: v[i * 51 + 10] for i, n in enumerate(NAMES) if len(v) > i * 51 + 10}
