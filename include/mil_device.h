@@ -95,8 +95,8 @@ int mil_affine_resample(float *d_out, const float *d_src, int ox, int oy, int oz
 int mil_corr_sums(const float *d_target, const float *d_src, int tx, int ty, int tz, int sx, int sy, int sz,
                   const float *m12, double *h_out, void *stream);
 /* The same two sums with the source held as a copy with a replicated one-voxel border ([sz+2][sy+2][sx+2]: the
- * texture unit's clamp addressing materialised in memory) -- the form mil_reg3d_affine evaluates ~10^3 times per
- * registration.  Bit-identical to mil_corr_sums.  create fails (-1) when the volumes are beyond the kernel's 32-bit
+ * texture unit's clamp addressing materialised in memory; kept both plain and as (row y, row y+1) pairs) -- the form
+ * mil_reg3d_affine evaluates ~10^3 times per registration.  Bit-identical to mil_corr_sums.  create fails (-1) when the volumes are beyond the kernel's 32-bit
  * offset range (mil_padded_source_eligible == 0); the caller then stays with mil_corr_sums. */
 typedef struct mil_padded_source mil_padded_source;
 int mil_padded_source_eligible(int tx, int ty, int tz, int sx, int sy, int sz);
@@ -104,6 +104,9 @@ int mil_padded_source_create(mil_padded_source **out, const float *d_src, int sx
 void mil_padded_source_destroy(mil_padded_source *p);
 int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, int tx, int ty, int tz,
                          const float *m12, double *h_out, void *stream);
+/* test / profiling aid (process-wide): pin the padded-source kernel -- 0 plain layout + plane reuse, 1 row-pair layout,
+ * 2 row-pair layout + plane reuse; -1 (default) chooses per matrix.  Every choice returns the same sums. */
+int mil_corr_padded_force_kernel(int kernel);
 /* reg3d_affine1, src/api_subfunc.cu:2733-2994, on device-resident volumes of equal size */
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records,

@@ -221,6 +221,10 @@ int mil_padded_source_create(mil_padded_source **out, const float *d_src, int sx
     });
 }
 void mil_padded_source_destroy(mil_padded_source *p) { delete p; }
+int mil_corr_padded_force_kernel(int kernel) {
+    k::corr_padded_force_kernel(kernel);
+    return 0;
+}
 int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, int tx, int ty, int tz,
                          const float *m12, double *h_out, void *stream) {
     return guarded("mil_corr_sums_padded", [&] {

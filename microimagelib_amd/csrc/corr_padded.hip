@@ -15,6 +15,10 @@
 // turns the six window compares into a bit-mask reduction that costs more than it saves.
 #include "kernels.h"
 
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
 namespace mil {
 namespace k {
 
@@ -130,7 +134,10 @@ __global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__re
 #pragma unroll 4
         for (int z = z0 + 1; z < z1; ++z) {
             toff += tstep;
-            const Step nxt = prepare(z, toff);
+            Step nxt = prepare(z, toff);
+            // a lane outside the window needs no data: let it ride on the offset the plane reuse expects, so it never
+            // triggers the (wave-wide) lower-plane gather; past the end of the buffer the gathers return 0
+            nxt.off = nxt.in ? nxt.off : cur.off + (unsigned)a.plane4;
             const f32x2 n0 = gather_pair(rsrc, nxt.off, s10), n1 = gather_pair(rsrc, nxt.off, s11);
             accumulate(cur, lo0, lo1, up0, up1);
             if (nxt.off != cur.off + (unsigned)a.plane4) {
@@ -166,6 +173,136 @@ __global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__re
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 gather_quad(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffset, (int)soffset, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// Row-pair layout: element (z, y, x) of the padded volume holds the float2 (src[z][y][x], src[z][y+1][x]), so ONE
+// 16-byte gather at (iz, iy, ix) returns the four taps of a source plane: (y0 x0, y1 x0, y0 x1, y1 x1).  Two gathers
+// per voxel whatever the matrix (no reuse between z steps to lose when lanes drift across planes), at the price of a
+// source stored -- and streamed from HBM -- twice.
+template <bool CACHE>
+__global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__restrict__ tgt,
+                                                              const float *__restrict__ srcp, PaddedArgs a,
+                                                              double *__restrict__ partials, int nblocks) {
+    __shared__ double lds[2 * kTileY];
+    const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
+    const int x = blockIdx.x * kTileX + lane;
+    const int y = blockIdx.y * kTileY + wave;
+    const int z0 = blockIdx.z * kStepsZ;
+    double ss = 0.0, st = 0.0;
+    if (x < a.tx && y < a.ty) {
+        const float ix = (float)x, iy = (float)y;
+        const int z1 = (z0 + kStepsZ < a.tz) ? z0 + kStepsZ : a.tz;
+        const f32x2 mxy0 = {a.m[0], a.m[4]}, mxy1 = {a.m[1], a.m[5]}, mxy2 = {a.m[2], a.m[6]}, mxy3 = {a.m[3], a.m[7]};
+        const f32x2 hxy = mxy0 * ix + mxy1 * iy;
+        const float hz = a.m[8] * ix + a.m[9] * iy;
+        const f32x2 half2 = {0.5f, 0.5f};
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(srcp), 0, (int)a.bytes, 0x00020000);
+        const unsigned s1 = (unsigned)a.plane4;  // here: plane pitch of the float2 volume, in bytes
+        const char *tbase = reinterpret_cast<const char *>(tgt);
+        unsigned toff = 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)y + (unsigned)a.ty * (unsigned)z0));
+        const unsigned tstep = 4u * (unsigned)a.tx * (unsigned)a.ty;
+        struct Step {
+            float wx0, wx1;
+            f32x2 wy, wz;
+            unsigned off;
+            bool in;
+            float tv;
+        };
+        auto prepare = [&](int z, unsigned toff) {
+            Step p;
+            const float iz = (float)z;
+            const f32x2 txy = ((hxy + mxy2 * iz) + mxy3) + half2;
+            const float tz = ((hz + a.m[10] * iz) + a.m[11]) + 0.5f;
+            const bool gx = txy.x > 0, lx = txy.x < a.sxf, gy = txy.y > 0, ly = txy.y < a.syf, gz = tz > 0, lz = tz < a.szf;
+            p.in = gx && lx && gy && ly && gz && lz;
+            const f32x2 bxy = txy - half2;
+            const float bz = tz - 0.5f;
+            const float fx = floorf(bxy.x), fy = floorf(bxy.y), fz = floorf(bz);
+            p.wx1 = bxy.x - fx;
+            p.wx0 = 1.0f - p.wx1;
+            p.wy.y = bxy.y - fy;
+            p.wy.x = 1.0f - p.wy.y;
+            p.wz.y = bz - fz;
+            p.wz.x = 1.0f - p.wz.y;
+            const unsigned off = (unsigned)(__mul24((int)fz, a.plane4) + __mul24((int)fy, a.row4) + a.origin4) +
+                                 ((unsigned)(int)fx << 3);
+            p.off = p.in ? off : 0u;
+            p.tv = *reinterpret_cast<const float *>(tbase + toff);
+            return p;
+        };
+        auto accumulate = [&](const Step &p, f32x4 lo, f32x4 up) {
+            const f32x2 lo_a = {lo.x, lo.y}, lo_b = {lo.z, lo.w}, up_a = {up.x, up.y}, up_b = {up.z, up.w};
+            const f32x2 cl = lo_a * p.wx0 + lo_b * p.wx1;  // (row y0, row y1) of the lower plane: w0*s(x0) + w1*s(x1)
+            const f32x2 cu = up_a * p.wx0 + up_b * p.wx1;
+            const f32x2 el = p.wy * cl, eu = p.wy * cu;
+            const f32x2 e = {el.x + el.y, eu.x + eu.y};
+            const f32x2 rz = p.wz * e;
+            const float r = rz.x + rz.y;
+            const float sv = __uint_as_float(p.in ? __float_as_uint(r) : 0u);
+            ss = __builtin_fma((double)sv, (double)sv, ss);
+            st = __builtin_fma((double)sv, (double)p.tv, st);
+        };
+        Step cur = prepare(z0, toff);
+        f32x4 lo = gather_quad(rsrc, cur.off, 0u), up = gather_quad(rsrc, cur.off, s1);
+#pragma unroll 4
+        for (int z = z0 + 1; z < z1; ++z) {
+            toff += tstep;
+            Step nxt = prepare(z, toff);
+            if (CACHE) nxt.off = nxt.in ? nxt.off : cur.off + s1;  // out of the window: never trigger the lower gather
+            const f32x4 nu = gather_quad(rsrc, nxt.off, s1);
+            f32x4 nl;
+            if (!CACHE) nl = gather_quad(rsrc, nxt.off, 0u);
+            accumulate(cur, lo, up);
+            if (CACHE) {
+                if (nxt.off != cur.off + s1) lo = gather_quad(rsrc, nxt.off, 0u);
+                else lo = up;
+            } else {
+                lo = nl;
+            }
+            up = nu;
+            cur = nxt;
+        }
+        accumulate(cur, lo, up);
+    }
+    ss = wave_sum(ss);
+    st = wave_sum(st);
+    if (lane == 0) {
+        lds[wave] = ss;
+        lds[kTileY + wave] = st;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTileY; ++w) {
+            a0 += lds[w];
+            a1 += lds[kTileY + w];
+        }
+        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        partials[b] = a0;
+        partials[nblocks + b] = a1;
+    }
+}
+
+// dst[z+1][y+1][x+1] = (src[z][y][x], src[z][y+1][x]) with edge replication; y runs over [-1, sy-1].
+__global__ __launch_bounds__(256) void pad_rowpair_kernel(float2 *__restrict__ dst, const float *__restrict__ src,
+                                                        int sx, int sy, int sz) {
+    const int xp = blockIdx.x * 256 + threadIdx.x, yp = blockIdx.y, zp = blockIdx.z;
+    if (xp >= sx + 2) return;
+    const int x = min(max(xp - 1, 0), sx - 1), z = min(max(zp - 1, 0), sz - 1);
+    const int y0 = min(max(yp - 1, 0), sy - 1), y1 = min(max(yp, 0), sy - 1);
+    const float *pl = src + (size_t)sx * sy * z;
+    dst[(size_t)xp + (size_t)(sx + 2) * ((size_t)yp + (size_t)(sy + 1) * zp)] =
+        make_float2(pl[(size_t)x + (size_t)sx * y0], pl[(size_t)x + (size_t)sx * y1]);
+}
+
 // dst[z+1][y+1][x+1] = src[z][y][x]; border voxels replicate the nearest edge voxel.
 __global__ __launch_bounds__(256) void pad_replicate_kernel(float *__restrict__ dst, const float *__restrict__ src,
                                                           int sx, int sy, int sz) {
@@ -187,6 +324,11 @@ bool PaddedSource::eligible(Dims t, Dims s) {
            zp < (1ll << 23) && t.nx <= (1 << 24) && t.ny <= (1 << 24) && t.nz <= (1 << 24);
 }
 
+bool PaddedSource::row_pairs_fit(Dims s) {
+    const long long xp = s.nx + 2, yp2 = s.ny + 1, zp = s.nz + 2;
+    return xp * yp2 * zp * 8 < (1ll << 31) && xp * yp2 * 8 < (1ll << 23);
+}
+
 void PaddedSource::build(const float *src, Dims d, hipStream_t s) {
     if (d.nx <= 0 || d.ny <= 0 || d.nz <= 0) throw Error(-1, "PaddedSource: empty volume");
     if (d.ny + 2 > 65535 || d.nz + 2 > 65535) throw Error(-1, "PaddedSource: volume exceeds launch limits");
@@ -196,7 +338,43 @@ void PaddedSource::build(const float *src, Dims d, hipStream_t s) {
     dim3 grid((unsigned)div_up(d.nx + 2, 256), (unsigned)(d.ny + 2), (unsigned)(d.nz + 2));
     hipLaunchKernelGGL(pad_replicate_kernel, grid, dim3(256), 0, s, data.get(), src, (int)d.nx, (int)d.ny, (int)d.nz);
     MIL_HIP(hipGetLastError());
+    has_pairs = row_pairs_fit(d);
+    if (has_pairs) {
+        const size_t n2 = (size_t)2 * (d.nx + 2) * (d.ny + 1) * (d.nz + 2);
+        if (pairs.size() < n2) pairs.alloc(n2);
+        dim3 grid2((unsigned)div_up(d.nx + 2, 256), (unsigned)(d.ny + 1), (unsigned)(d.nz + 2));
+        hipLaunchKernelGGL(pad_rowpair_kernel, grid2, dim3(256), 0, s, reinterpret_cast<float2 *>(pairs.get()), src,
+                           (int)d.nx, (int)d.ny, (int)d.nz);
+        MIL_HIP(hipGetLastError());
+    }
 }
+
+namespace {
+
+// Which kernel serves this matrix best (measured at 512x512x256, tools/bench_corr.py --sweep; all three give the same
+// sums).  The plane reuse of corr_padded_kernel skips a gather only when EVERY lane of a wave reuses, so what counts is
+// how often, per z step, some lane of a 64-wide wave crosses a source column, row or plane out of turn: the crossing rate
+// of one lane (|m2|, |m6|, |m10 - 1| per step) times the number of distinct phases the wave's lanes carry
+// (1 + 64 * distance of the per-x increment m0 / m4 / m8 from an integer, at most 64).
+//   < 0.08  plain layout + plane reuse           (translations, pure scales, rotations up to ~2 degrees)
+//   < 0.6   row pairs + plane reuse              (the usual registration matrix: a few degrees AND a few per cent)
+//   else    row pairs, both planes gathered      (large rotations)
+int g_forced_kernel = -1;  // test / profiling aid, corr_padded_force_kernel()
+
+int pick_kernel(const float *m, bool has_pairs) {
+    if (!has_pairs) return 0;
+    if (g_forced_kernel >= 0 && g_forced_kernel <= 2) return g_forced_kernel;
+    auto frac_dist = [](double v) { return std::fabs(v - std::nearbyint(v)); };
+    auto phases = [&](double per_x) { return std::min(64.0, 1.0 + 64.0 * frac_dist(per_x)); };
+    const double rate = std::fabs((double)m[2]) * phases(m[0]) + std::fabs((double)m[6]) * phases(m[4]) +
+                        std::fabs((double)m[10] - 1.0) * phases(m[8]);
+    if (!(rate >= 0.08)) return 0;  // also NaN
+    return rate < 0.6 ? 2 : 1;
+}
+
+}  // namespace
+
+void corr_padded_force_kernel(int kernel) { g_forced_kernel = kernel; }
 
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
                             hipStream_t s) {
@@ -206,18 +384,32 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
     for (int i = 0; i < 12; ++i) a.m[i] = m.m[i];
     a.tx = (int)t.nx; a.ty = (int)t.ny; a.tz = (int)t.nz;
     a.sxf = (float)src.dims.nx; a.syf = (float)src.dims.ny; a.szf = (float)src.dims.nz;
-    const long long xp = src.dims.nx + 2, yp = src.dims.ny + 2;
-    a.row4 = (int)(4 * xp);
-    a.plane4 = (int)(4 * xp * yp);
-    a.origin4 = (int)(4 * (xp * yp + xp + 1));
-    a.bytes = (unsigned)(4 * xp * yp * (src.dims.nz + 2));
+    const long long xp = src.dims.nx + 2, yp = src.dims.ny + 2, yp2 = src.dims.ny + 1, zp = src.dims.nz + 2;
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kStepsZ - 1) / kStepsZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
     if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
-    hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, ws.partials.get(),
-                       (int)nblocks);
+    const int kernel = pick_kernel(a.m, src.has_pairs);
+    if (kernel != 0) {  // float2 volume [sz+2][sy+1][sx+2]
+        a.row4 = (int)(8 * xp);
+        a.plane4 = (int)(8 * xp * yp2);
+        a.origin4 = (int)(8 * ((yp2 + 1) * xp + 1));
+        a.bytes = (unsigned)(8 * xp * yp2 * zp);
+        if (kernel == 2)
+            hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a,
+                               ws.partials.get(), (int)nblocks);
+        else
+            hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a,
+                               ws.partials.get(), (int)nblocks);
+    } else {            // float volume [sz+2][sy+2][sx+2]
+        a.row4 = (int)(4 * xp);
+        a.plane4 = (int)(4 * xp * yp);
+        a.origin4 = (int)(4 * (xp * yp + xp + 1));
+        a.bytes = (unsigned)(4 * xp * yp * zp);
+        hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, ws.partials.get(),
+                           (int)nblocks);
+    }
     MIL_HIP(hipGetLastError());
     corr_final_launch(ws, nblocks, s);
 }

@@ -96,17 +96,24 @@ void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_d
                     CorrWorkspace &ws, hipStream_t s, double *ss, double *st, bool float_products = false);
 
 
-// Source volume with a one-voxel replicated border, [sz+2][sy+2][sx+2]: the border stands in for the texture unit's
-// clamp addressing, so the cost kernel needs neither index clamps nor edge selects (affine.hip).  Same sums, bit for
-// bit, as corr_sums_* on the unpadded volume.
+// Source volume of the 3-D registration with a one-voxel replicated border -- the texture unit's clamp addressing
+// materialised in memory, so the cost kernels need neither index clamps nor edge selects (corr_padded.hip).  Held twice:
+// plain, [sz+2][sy+2][sx+2] floats, and as row pairs, [sz+2][sy+1][sx+2] float2 = (row y, row y+1), which turns the four
+// taps of a source plane into ONE 16-byte gather.  corr_sums_padded_* pick the kernel per matrix; every choice returns
+// the same sums, bit for bit, as corr_sums_* on the unpadded volume.
 struct PaddedSource {
-    DeviceBuffer<float> data;
+    DeviceBuffer<float> data;   // plain layout
+    DeviceBuffer<float> pairs;  // row-pair layout (absent when it would exceed the kernels' 32-bit offsets)
+    bool has_pairs = false;
     Dims dims{0, 0, 0};  // unpadded extents
     static bool eligible(Dims target, Dims source);  // all byte offsets fit 32 bits
+    static bool row_pairs_fit(Dims source);
     void build(const float *src, Dims dims, hipStream_t s);
 };
 // second stage of every cost evaluation: sums the per-workgroup partials into ws.host (pinned)
 void corr_final_launch(CorrWorkspace &ws, size_t nblocks, hipStream_t s);
+// test / profiling aid: 0 plain + plane reuse | 1 row pairs | 2 row pairs + plane reuse | -1 (default) per matrix
+void corr_padded_force_kernel(int kernel);
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t_dims, const Affine12 &m,
                             CorrWorkspace &ws, hipStream_t s);
 void corr_sums_padded_sync(const float *target, const PaddedSource &src, Dims t_dims, const Affine12 &m,

@@ -142,6 +142,12 @@ class PaddedSource:
             pass
 
 
+def corr_padded_force_kernel(kernel: int = -1):
+    """Test / profiling aid: pin the padded-source cost kernel (0 plain + plane reuse, 1 row pairs, 2 row pairs + plane
+    reuse); -1 restores the per-matrix choice."""
+    _lib.load().mil_corr_padded_force_kernel(int(kernel))
+
+
 def corr_sums(target: torch.Tensor, src, m12, stream=None):
     m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)
     out = (C.c_double * 2)()

@@ -194,15 +194,19 @@ def _bits(v):
 
 
 def test_padded_cost_kernel_is_bit_identical(dev):
-    """The registration's cost kernel reads the source through a border-padded copy (csrc/corr_padded.hip): same two
-    sums, bit for bit, as the general kernel -- golden matrices (texel centres, edges, all-out-of-window), random
+    """The registration's cost kernels read the source through border-padded copies (csrc/corr_padded.hip: plain and
+    row-pair layouts, with and without plane reuse): same two sums, bit for bit, as the general kernel -- golden matrices (texel centres, edges, all-out-of-window), random
     affine matrices, and matrices that put many voxels on the replicated border."""
     g = np.load(os.path.join(GOLD, "affine.npz"))
     src, tgt = T(g["src"]), T(g["tgt"])
     pad = dev.PaddedSource(src)
     for i, m in enumerate(g["mats"]):
-        a, b = dev.corr_sums(tgt, src, m), dev.corr_sums(tgt, pad, m)
-        assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"golden matrix {i}"
+        a = dev.corr_sums(tgt, src, m)
+        for kern in (-1, 0, 1, 2):  # per-matrix choice, then each of the three padded-source kernels
+            dev.corr_padded_force_kernel(kern)
+            b = dev.corr_sums(tgt, pad, m)
+            assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"golden matrix {i}, kernel {kern}"
+        dev.corr_padded_force_kernel(-1)
         want_ss, want_st = g["corr_sums"][i]
         assert abs(b[0] - want_ss) <= 1e-12 * max(abs(want_ss), 1e-30)
         assert abs(b[1] - want_st) <= 1e-11 * max(abs(want_ss), 1e-30)
@@ -228,8 +232,12 @@ def test_padded_cost_kernel_is_bit_identical(dev):
         mats.append(np.full(12, 1e30, dtype=f32))           # overflows to inf / nan: all out of the window
         mats.append(np.full(12, np.nan, dtype=f32))
         for i, m in enumerate(mats):
-            a, b = dev.corr_sums(dt, ds, m), dev.corr_sums(dt, pad, m)
-            assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"{shape_s} matrix {i}"
+            a = dev.corr_sums(dt, ds, m)
+            for kern in (-1, 0, 1, 2):
+                dev.corr_padded_force_kernel(kern)
+                b = dev.corr_sums(dt, pad, m)
+                assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"{shape_s} matrix {i}, kernel {kern}"
+            dev.corr_padded_force_kernel(-1)
             if i < 11:
                 wss, wst = ro.corr_sums(tgt, src, m)
                 assert abs(b[0] - wss) <= 1e-12 * max(wss, 1e-30) and abs(b[1] - wst) <= 1e-11 * max(wss, 1e-30)

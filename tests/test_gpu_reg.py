@@ -282,8 +282,16 @@ def test_full_size_registration_properties(dev):
     c, s_ = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
     rot[[0, 2, 8, 10]] = np.array([c, -s_, s_, c], dtype=np.float32) * np.float32(1.02)
     rot[[3, 7, 11]] = (7.0, -3.0, -11.0)
-    for m in (ident, rot):
-        assert dev.corr_sums(ms, pad, m) == dev.corr_sums(ms, ms, m)
+    rot20 = ident.copy()
+    c, s_ = np.cos(np.deg2rad(20.0)), np.sin(np.deg2rad(20.0))
+    rot20[[0, 1, 4, 5]] = np.array([c, -s_, s_, c], dtype=np.float32)
+    rot20[[3, 7]] = (90.0, -80.0)
+    for m in (ident, rot, rot20):
+        want = dev.corr_sums(ms, ms, m)
+        for kern in (-1, 0, 1, 2):
+            dev.corr_padded_force_kernel(kern)
+            assert dev.corr_sums(ms, pad, m) == want, f"kernel {kern}"
+    dev.corr_padded_force_kernel(-1)
     pad.close()
     assert abs(ss2 - ss) <= 1e-12 * ss and abs(st2 - 2.0 * st) <= 1e-9 * abs(st)
     shift = ident.copy()
