@@ -19,6 +19,7 @@
 // and a z-marching ring of source planes with an 8-deep register prefetch FIFO) were built and
 // measured SLOWER (0.36 and 0.43 ms per evaluation against 0.215 ms): the staging and ring
 // bookkeeping add more VALU work than the gathers they remove.  They live in the git history only.
+#include "corr_finish.h"
 #include "kernels.h"
 
 #include <cstdlib>
@@ -175,9 +176,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // CACHE: reuse the previous step's upper source plane when it is this step's lower one (needs sx >= 2).
 template <bool FLOAT_PRODUCTS, bool CACHE>
 __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__restrict__ tgt,
-                                                           const float *__restrict__ src, AffineArgs a,
-                                                           double *__restrict__ partials, int nblocks) {
+                                                           const float *__restrict__ src, AffineArgs a, CorrTail tail) {
     __shared__ double lds[2 * kTileY];
+    __shared__ int last;
     const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
     const int x = blockIdx.x * kTileX + lane;
     const int y = blockIdx.y * kTileY + wave;
@@ -218,45 +219,15 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
         lds[kTileY + wave] = st;
     }
     __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
     if (threadIdx.x == 0) {
-        double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int w = 0; w < kTileY; ++w) {
             a0 += lds[w];
             a1 += lds[kTileY + w];
         }
-        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        partials[b] = a0;
-        partials[nblocks + b] = a1;
     }
-}
-
-constexpr int kFinalThreads = 1024;
-__global__ __launch_bounds__(kFinalThreads) void corr_final_kernel(const double *__restrict__ partials, int count,
-                                                                 double *__restrict__ out) {
-    __shared__ double lds[2 * (kFinalThreads / 64)];
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = threadIdx.x; i < count; i += kFinalThreads) {
-        a0 += partials[i];
-        a1 += partials[count + i];
-    }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        lds[wave] = a0;
-        lds[kFinalThreads / 64 + wave] = a1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double r0 = 0.0, r1 = 0.0;
-        for (int w = 0; w < kFinalThreads / 64; ++w) {
-            r0 += lds[w];
-            r1 += lds[kFinalThreads / 64 + w];
-        }
-        out[0] = r0;
-        out[1] = r1;
-    }
+    corr_publish<kBlockThreads>(a0, a1, tail, lds, &last);
 }
 
 AffineArgs make_args(Dims t, Dims s, const Affine12 &m) {
@@ -284,9 +255,45 @@ void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims,
     MIL_HIP(hipGetLastError());
 }
 
-CorrWorkspace::CorrWorkspace() { MIL_HIP(hipHostMalloc((void **)&host, 2 * sizeof(double), hipHostMallocDefault)); }
+CorrWorkspace::CorrWorkspace() {
+    // coherent: the kernel's system-scope store of the ticket is visible to the polling host while the stream runs on
+    MIL_HIP(hipHostMalloc((void **)&host, 3 * sizeof(double), hipHostMallocCoherent));
+    host[0] = host[1] = host[2] = 0.0;
+    counter.alloc(kCorrCounters + 1);
+    MIL_HIP(hipMemset(counter.get(), 0, (kCorrCounters + 1) * sizeof(unsigned)));
+}
 CorrWorkspace::~CorrWorkspace() {
     if (host) (void)hipHostFree(host);
+}
+
+CorrTail CorrWorkspace::next(size_t nblocks) {
+    // a group of the two-level tail holds nblocks / kCorrCounters partials and one 256-thread workgroup sums it with
+    // 8 loads per thread (corr_finish.h): 131 072 workgroups = 2048 x 2048 x 512 target voxels
+    if (nblocks == 0 || nblocks > (size_t)kCorrCounters * 8 * 256) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    if (partials.size() < 2 * nblocks + 2 * kCorrCounters) partials.alloc(2 * nblocks + 2 * kCorrCounters);
+    ticket += 1.0;
+    return CorrTail{partials.get(), (int)nblocks, counter.get(), host, ticket};
+}
+
+void CorrWorkspace::wait(hipStream_t s) const {
+    // The last workgroup stores the ticket after the sums (release, system scope).  Poll it: a stream synchronisation
+    // costs ~10 us more per evaluation.  Should the ticket not show up in ~50 ms (a failed launch), fall back to the
+    // synchronisation, which reports the error.
+    volatile const double *flag = host + 2;
+    static const bool no_poll = getenv("MIL_CORR_POLL") && getenv("MIL_CORR_POLL")[0] == '0';
+    if (no_poll) {
+        MIL_HIP(hipStreamSynchronize(s));
+        return;
+    }
+    for (long spin = 0; spin < 20000000L; ++spin) {
+        if (*flag == ticket) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return;
+        }
+        __builtin_ia32_pause();
+    }
+    MIL_HIP(hipStreamSynchronize(s));
+    if (*flag != ticket) throw Error(-1, "corr_sums: the cost kernel did not publish its result");
 }
 
 void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
@@ -294,33 +301,21 @@ void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_
     AffineArgs a = make_args(t_dims, s_dims, m);
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
-    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
-    if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
-    if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
+    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
     static const bool no_cache = getenv("MIL_CORR_NOCACHE") && getenv("MIL_CORR_NOCACHE")[0] == '1';
     if (float_products)  // 2-D images (one plane): nothing to reuse along z
-        hipLaunchKernelGGL((corr_kernel<true, false>), grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
-                           (int)nblocks);
+        hipLaunchKernelGGL((corr_kernel<true, false>), grid, dim3(kBlockThreads), 0, s, target, src, a, tail);
     else if (a.sx >= 2 && !no_cache)
-        hipLaunchKernelGGL((corr_kernel<false, true>), grid, dim3(kBlockThreads), 0, s, target, src, a, ws.partials.get(),
-                           (int)nblocks);
+        hipLaunchKernelGGL((corr_kernel<false, true>), grid, dim3(kBlockThreads), 0, s, target, src, a, tail);
     else
-        hipLaunchKernelGGL((corr_kernel<false, false>), grid, dim3(kBlockThreads), 0, s, target, src, a,
-                           ws.partials.get(), (int)nblocks);
-    MIL_HIP(hipGetLastError());
-    // the final pass writes (ss, st) straight into pinned host memory: no copy node, one stream sync per evaluation
-    corr_final_launch(ws, nblocks, s);
-}
-
-void corr_final_launch(CorrWorkspace &ws, size_t nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(kFinalThreads), 0, s, ws.partials.get(), (int)nblocks, ws.host);
+        hipLaunchKernelGGL((corr_kernel<false, false>), grid, dim3(kBlockThreads), 0, s, target, src, a, tail);
     MIL_HIP(hipGetLastError());
 }
 
 void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
                     CorrWorkspace &ws, hipStream_t s, double *ss, double *st, bool float_products) {
     corr_sums_async(target, src, t_dims, s_dims, m, ws, s, float_products);
-    MIL_HIP(hipStreamSynchronize(s));
+    ws.wait(s);
     *ss = ws.host[0];
     *st = ws.host[1];
 }

@@ -1,0 +1,120 @@
+// Tail of every registration cost kernel: the workgroup that finishes LAST sums the per-workgroup partials -- in an
+// order that does not depend on which workgroup that is -- and publishes {sum s*s, sum s*t, ticket} to pinned host
+// memory.  One launch per evaluation instead of two (the reference uses three plus two host loops,
+// src/api_subfunc.cu:954-988), and the host learns the result by polling the ticket instead of a stream
+// synchronisation: ~15 us less per evaluation, of ~165.
+#pragma once
+
+#include "kernels.h"
+
+namespace mil {
+namespace k {
+
+__device__ __forceinline__ double corr_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Visibility between workgroups (which may sit on different XCDs, each with its own L2) WITHOUT release / acquire
+// fences: an agent-scope fence is a write-back + invalidate of the whole L2 (buffer_wbl2 sc1 / buffer_inv sc1), measured
+// at ~6 us apiece -- 0.75 ms per evaluation with one per workgroup.  Instead every datum that crosses workgroups is
+// itself stored and loaded at agent scope (sc1: written through to / read from the memory side), and a workgroup waits
+// for its stores to be acknowledged (s_waitcnt vmcnt(0)) before it counts itself done.
+__device__ __forceinline__ void corr_store_agent(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double corr_load_agent(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void corr_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned corr_count(unsigned *c) {
+    return __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sum of n (ss, st) pairs p[i * stride], q[i * stride] in a fixed order: thread-strided, then waves, then thread 0.
+// All loads of a thread are issued before the first add (n <= 8 * THREADS per call site), so the tail costs one
+// memory round trip, not one per element.  Result valid in thread 0.
+template <int THREADS>
+__device__ __forceinline__ void corr_block_sum(const double *p, const double *q, int n, int stride, double *lds,
+                                               double &r0, double &r1) {
+    constexpr int WAVES = THREADS / 64;
+    double v0[8], v1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = (int)threadIdx.x + k * THREADS;
+        const bool ok = i < n;
+        v0[k] = ok ? corr_load_agent(p + (size_t)i * stride) : 0.0;
+        v1[k] = ok ? corr_load_agent(q + (size_t)i * stride) : 0.0;
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s0 += v0[k];
+        s1 += v1[k];
+    }
+    s0 = corr_wave_sum(s0);
+    s1 = corr_wave_sum(s1);
+    __syncthreads();  // lds may still be in use by the caller's previous reduction
+    if ((threadIdx.x & 63) == 0) {
+        lds[threadIdx.x >> 6] = s0;
+        lds[WAVES + (threadIdx.x >> 6)] = s1;
+    }
+    __syncthreads();
+    r0 = r1 = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            r0 += lds[w];
+            r1 += lds[WAVES + w];
+        }
+    }
+}
+
+// Call from all THREADS threads of the workgroup; (a0, a1) = this workgroup's sums, valid in thread 0.
+// lds: >= 2 * (THREADS / 64) doubles; flag: one int of shared memory.
+//
+// Two levels, both for the count and for the sum: workgroup b belongs to group b % G (G = kCorrCounters).  The last
+// workgroup of a group to finish sums that group's partials into the group slot; the last GROUP to finish sums the G
+// slots and publishes.  (~3 * 10^4 workgroups on ONE counter serialise in the memory-side atomic unit, and one
+// workgroup summing 6 * 10^4 doubles alone is a long latency-bound tail.)  Which workgroup is "last" varies from run to
+// run; what it adds, and in which order, does not.
+template <int THREADS>
+__device__ __forceinline__ void corr_publish(double a0, double a1, CorrTail t, double *lds, int *flag) {
+    const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int groups = t.nblocks < kCorrCounters ? t.nblocks : kCorrCounters;
+    const int grp = b % groups;
+    const int members = (t.nblocks - grp + groups - 1) / groups;  // <= 8 * THREADS, checked by CorrWorkspace::next
+    double *gsum = t.partials + 2 * (size_t)t.nblocks;             // [2][kCorrCounters]
+    if (threadIdx.x == 0) {
+        corr_store_agent(t.partials + b, a0);
+        corr_store_agent(t.partials + t.nblocks + b, a1);
+        corr_stores_done();
+        *flag = corr_count(t.counter + grp) == (unsigned)members - 1u;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    double r0, r1;
+    corr_block_sum<THREADS>(t.partials + grp, t.partials + t.nblocks + grp, members, groups, lds, r0, r1);
+    if (threadIdx.x == 0) {
+        corr_store_agent(gsum + grp, r0);
+        corr_store_agent(gsum + kCorrCounters + grp, r1);
+        corr_stores_done();
+        *flag = corr_count(t.counter + kCorrCounters) == (unsigned)groups - 1u;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    corr_block_sum<THREADS>(gsum, gsum + kCorrCounters, groups, 1, lds, r0, r1);
+    if (threadIdx.x == 0) {
+        // ready for the next evaluation: kernels of one stream run in order, and the end of a kernel writes L2 back
+        for (int i = 0; i <= kCorrCounters; ++i)
+            __hip_atomic_store(t.counter + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(t.host + 0, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(t.host + 1, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        corr_stores_done();  // the sums are in host memory before the ticket that announces them
+        __hip_atomic_store(t.host + 2, t.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace k
+}  // namespace mil

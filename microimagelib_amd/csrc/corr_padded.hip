@@ -13,6 +13,7 @@
 // corr_kernel's on the unpadded volume.  The kernel is VALU-issue bound, so the arithmetic is written in explicit
 // 2-wide vectors (v_pk_mul_f32 / v_pk_add_f32) and this file is compiled with the SLP vectoriser off -- left on, it
 // turns the six window compares into a bit-mask reduction that costs more than it saves.
+#include "corr_finish.h"
 #include "kernels.h"
 
 #include <algorithm>
@@ -48,16 +49,11 @@ __device__ __forceinline__ f32x2 gather_pair(__amdgpu_buffer_rsrc_t rsrc, unsign
     return __builtin_bit_cast(f32x2, v);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
 __global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__restrict__ tgt,
                                                              const float *__restrict__ srcp, PaddedArgs a,
-                                                             double *__restrict__ partials, int nblocks) {
+                                                             CorrTail tail) {
     __shared__ double lds[2 * kTileY];
+    __shared__ int last;
     const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
     const int x = blockIdx.x * kTileX + lane;
     const int y = blockIdx.y * kTileY + wave;
@@ -153,24 +149,22 @@ __global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__re
         }
         accumulate(cur, lo0, lo1, up0, up1);
     }
-    ss = wave_sum(ss);
-    st = wave_sum(st);
+    ss = corr_wave_sum(ss);
+    st = corr_wave_sum(st);
     if (lane == 0) {
         lds[wave] = ss;
         lds[kTileY + wave] = st;
     }
     __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
     if (threadIdx.x == 0) {
-        double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int w = 0; w < kTileY; ++w) {
             a0 += lds[w];
             a1 += lds[kTileY + w];
         }
-        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        partials[b] = a0;
-        partials[nblocks + b] = a1;
     }
+    corr_publish<kThreads>(a0, a1, tail, lds, &last);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -188,8 +182,9 @@ __device__ __forceinline__ f32x4 gather_quad(__amdgpu_buffer_rsrc_t rsrc, unsign
 template <bool CACHE>
 __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__restrict__ tgt,
                                                               const float *__restrict__ srcp, PaddedArgs a,
-                                                              double *__restrict__ partials, int nblocks) {
+                                                              CorrTail tail) {
     __shared__ double lds[2 * kTileY];
+    __shared__ int last;
     const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
     const int x = blockIdx.x * kTileX + lane;
     const int y = blockIdx.y * kTileY + wave;
@@ -271,24 +266,22 @@ __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__r
         }
         accumulate(cur, lo, up);
     }
-    ss = wave_sum(ss);
-    st = wave_sum(st);
+    ss = corr_wave_sum(ss);
+    st = corr_wave_sum(st);
     if (lane == 0) {
         lds[wave] = ss;
         lds[kTileY + wave] = st;
     }
     __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
     if (threadIdx.x == 0) {
-        double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int w = 0; w < kTileY; ++w) {
             a0 += lds[w];
             a1 += lds[kTileY + w];
         }
-        const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        partials[b] = a0;
-        partials[nblocks + b] = a1;
     }
+    corr_publish<kThreads>(a0, a1, tail, lds, &last);
 }
 
 // dst[z+1][y+1][x+1] = (src[z][y][x], src[z][y+1][x]) with edge replication; y runs over [-1, sy-1].
@@ -387,9 +380,7 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
     const long long xp = src.dims.nx + 2, yp = src.dims.ny + 2, yp2 = src.dims.ny + 1, zp = src.dims.nz + 2;
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kStepsZ - 1) / kStepsZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
-    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
-    if (nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: too many workgroups");
-    if (ws.partials.size() < 2 * nblocks + 2) ws.partials.alloc(2 * nblocks + 2);
+    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
     const int kernel = pick_kernel(a.m, src.has_pairs);
     if (kernel != 0) {  // float2 volume [sz+2][sy+1][sx+2]
         a.row4 = (int)(8 * xp);
@@ -397,27 +388,23 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
         a.origin4 = (int)(8 * ((yp2 + 1) * xp + 1));
         a.bytes = (unsigned)(8 * xp * yp2 * zp);
         if (kernel == 2)
-            hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a,
-                               ws.partials.get(), (int)nblocks);
+            hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a, tail);
         else
-            hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a,
-                               ws.partials.get(), (int)nblocks);
+            hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a, tail);
     } else {            // float volume [sz+2][sy+2][sx+2]
         a.row4 = (int)(4 * xp);
         a.plane4 = (int)(4 * xp * yp);
         a.origin4 = (int)(4 * (xp * yp + xp + 1));
         a.bytes = (unsigned)(4 * xp * yp * zp);
-        hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, ws.partials.get(),
-                           (int)nblocks);
+        hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail);
     }
     MIL_HIP(hipGetLastError());
-    corr_final_launch(ws, nblocks, s);
 }
 
 void corr_sums_padded_sync(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
                            hipStream_t s, double *ss, double *st) {
     corr_sums_padded_async(target, src, t, m, ws, s);
-    MIL_HIP(hipStreamSynchronize(s));
+    ws.wait(s);
     *ss = ws.host[0];
     *st = ws.host[1];
 }

@@ -79,16 +79,28 @@ struct Affine12 {
 // strict_window: lower bound 0 < t instead of 0 <= t (the reference's 2-D transform kernel).
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m,
                      hipStream_t s, bool strict_window = false);
+constexpr int kCorrCounters = 64;  // first-level completion counters of a cost kernel (+ 1 top-level)
+struct CorrTail {  // what the last workgroup of a cost kernel needs (corr_finish.h)
+    double *partials;   // [2][nblocks]
+    int nblocks;
+    unsigned *counter;  // [kCorrCounters + 1] workgroups finished so far, by group, and groups finished
+    double *host;       // pinned {sum s*s, sum s*t, ticket}
+    double ticket;
+};
 struct CorrWorkspace {
-    DeviceBuffer<double> partials;  // 2 * kMaxCorrBlocks
-    double *host = nullptr;         // pinned: {sum s*s, sum s*t}
+    DeviceBuffer<double> partials;
+    DeviceBuffer<unsigned> counter;
+    double *host = nullptr;  // pinned, coherent: {sum s*s, sum s*t, ticket of the evaluation they belong to}
+    double ticket = 0.0;     // evaluations launched with this workspace
     CorrWorkspace();
     ~CorrWorkspace();
     CorrWorkspace(const CorrWorkspace &) = delete;
     CorrWorkspace &operator=(const CorrWorkspace &) = delete;
+    CorrTail next(size_t nblocks);        // sizes the partials, takes a ticket
+    void wait(hipStream_t s) const;       // until the evaluation of the last ticket has published its sums
 };
-// Enqueue the fused interpolate + correlate + reduce; result lands in ws.host after
-// the stream is synchronised (corr_sums_sync does that and returns it).
+// Enqueue the fused interpolate + correlate + reduce (ONE launch); the result lands in ws.host, ws.wait() returns
+// once it is there (corr_sums_sync does both).
 // float_products: form s*s and s*t in float32 before the float64 sums (the reference's 2-D cost).
 void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,
                      CorrWorkspace &ws, hipStream_t s, bool float_products = false);
@@ -110,8 +122,6 @@ struct PaddedSource {
     static bool row_pairs_fit(Dims source);
     void build(const float *src, Dims dims, hipStream_t s);
 };
-// second stage of every cost evaluation: sums the per-workgroup partials into ws.host (pinned)
-void corr_final_launch(CorrWorkspace &ws, size_t nblocks, hipStream_t s);
 // test / profiling aid: 0 plain + plane reuse | 1 row pairs | 2 row pairs + plane reuse | -1 (default) per matrix
 void corr_padded_force_kernel(int kernel);
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t_dims, const Affine12 &m,

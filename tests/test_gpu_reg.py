@@ -292,6 +292,12 @@ def test_full_size_registration_properties(dev):
             dev.corr_padded_force_kernel(kern)
             assert dev.corr_sums(ms, pad, m) == want, f"kernel {kern}"
     dev.corr_padded_force_kernel(-1)
+    # The last workgroup to finish sums the partials of all the others, which reach it through agent-scope stores and
+    # loads instead of fences (csrc/corr_finish.h): 200 evaluations at full size must all publish the same bits.
+    first = dev.corr_sums(ms, pad, rot)
+    assert all(dev.corr_sums(ms, pad, rot) == first for _ in range(200))
+    first = dev.corr_sums(ms, ms, rot)
+    assert all(dev.corr_sums(ms, ms, rot) == first for _ in range(50))
     pad.close()
     assert abs(ss2 - ss) <= 1e-12 * ss and abs(st2 - 2.0 * st) <= 1e-9 * abs(st)
     shift = ident.copy()
