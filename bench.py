@@ -11,8 +11,8 @@ collective on the data path; the only exchange is the gather of the XY maximum-i
 projections to rank 0 after the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      HBM roofline of the fused estimate-update kernel, timed with HIP events on
-                the engine's stream inside the timed region;
+  roofline      HBM roofline of the dominant kernel (the in-place y pass of the fused backend), timed
+                with HIP events on the engine's stream inside the timed region;
   cpu_baseline  the oracle's NumPy restatement of the same RL iteration timed on this box's
                 host cores (N = 1 only), a bounded sample;
   extra         dual-view it/s, reg3D voxels/s and the per-kernel-family time split.
@@ -65,9 +65,22 @@ def gaussian_psf(shape, sigma_zyx):
     return (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
 
 
-def cpu_baseline(img_host, psf_host, iters):
-    """Oracle (NumPy restatement of decon_singleview_OTF1) on the host: `iters` RL iterations."""
+def cpu_baseline(img_host, psf_host, iters, fft_workers=1):
+    """Oracle (NumPy restatement of decon_singleview_OTF1) on the host: `iters` RL iterations.
+
+    fft_workers > 1: the transforms run on scipy.fft's thread pool (same pocketfft code, multi-threaded), the
+    element-wise passes stay single-threaded -- the reference's CPU path threads nothing but the FFT either."""
     from oracle import decon_oracle as do
+    if fft_workers > 1:
+        import scipy.fft as sfft
+        saved = (do.r2c, do.c2r)
+        do.r2c = lambda a: sfft.rfftn(a.astype(np.float32, copy=False), workers=fft_workers)
+        do.c2r = lambda s, F: sfft.irfftn(s, s=F, axes=(0, 1, 2), norm="forward", workers=fft_workers).astype(
+            np.float32, copy=False)
+        try:
+            return cpu_baseline(img_host, psf_host, iters, 1)
+        finally:
+            do.r2c, do.c2r = saved
     F = img_host.shape
     otf = do.gen_otf(psf_host, F)
     otf_bp = do.gen_otf(do.flip3(psf_host), F)
@@ -94,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--cpu-fft-threads", type=int, default=16,
+                    help="second CPU figure with the FFTs threaded (a 1-GPU box's share of host cores); 1 = skip")
     ap.add_argument("--backend", choices=["auto", "rocfft", "fused"], default="auto",
                     help="transform backend of the RL engine (auto = fused LDS-tiled kernels on power-of-two boxes)")
     args = ap.parse_args()
@@ -346,6 +361,12 @@ def main():
                       f"(oracle/decon_oracle.py: NumPy pocketfft float32 + single-threaded element-wise), {secs:.1f} s",
             "host_cores_available": os.cpu_count(),
         }
+        if args.cpu_fft_threads > 1:
+            its_mt, secs_mt = cpu_baseline(img_host, psf_a_host, args.cpu_iters, args.cpu_fft_threads)
+            result["cpu_baseline"]["fft_threaded"] = {
+                "value": round(its_mt, 4), "unit": "iterations/s", "cores": args.cpu_fft_threads,
+                "sample": f"same {args.cpu_iters} iterations with the transforms on {args.cpu_fft_threads} threads "
+                          f"(scipy.fft workers; element-wise passes single-threaded as in the reference), {secs_mt:.1f} s"}
     elif rank == 0:
         result["cpu_baseline"] = None
 

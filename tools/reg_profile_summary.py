@@ -9,7 +9,7 @@ NAMES = ["identity", "rot3_scale1.02", "rot10", "rot45"]  # order and 51 launche
 
 
 def is_cost(name):
-    return "corr_kernel" in name or "corr_padded_kernel" in name
+    return any(k in name for k in ("corr_kernel", "corr_padded_kernel", "corr_rowpair_kernel"))
 
 
 def newest(pattern):
@@ -25,9 +25,7 @@ def main(src, dst):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     out["kernel_us_median"] = {n: sorted(d[i * 51:(i + 1) * 51])[25] for i, n in enumerate(NAMES)}
-    fin = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
-                 if "corr_final" in r["Kernel_Name"])
-    out["final_kernel_us_median"] = fin[len(fin) // 2]
+    out["kernels"] = {n: rows[i * 51 + 10]["Kernel_Name"].split("(")[0].split("::")[-1] for i, n in enumerate(NAMES)}
     out["counters"] = {}
     for pm in ("reg_pmc1", "reg_pmc2", "reg_pmc3"):
         f = newest(os.path.join(src, pm, "**", "*_counter_collection.csv"))
