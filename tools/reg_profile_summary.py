@@ -3,7 +3,7 @@
 
     python tools/reg_profile_summary.py gpurun_out/r01_final profiles/r01_final
 """
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
 
 NAMES = ["identity", "rot3_scale1.02", "rot10", "rot45"]  # order and 51 launches each: tools/bench_corr.py
 
@@ -25,7 +25,7 @@ def main(src, dst):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     out["kernel_us_median"] = {n: sorted(d[i * 51:(i + 1) * 51])[25] for i, n in enumerate(NAMES)}
-    out["kernels"] = {n: rows[i * 51 + 10]["Kernel_Name"].split("(")[0].split("::")[-1] for i, n in enumerate(NAMES)}
+    out["kernels"] = {n: re.search(r"corr_\w+(<\w+>)?", rows[i * 51 + 10]["Kernel_Name"]).group(0) for i, n in enumerate(NAMES)}
     out["counters"] = {}
     for pm in ("reg_pmc1", "reg_pmc2", "reg_pmc3"):
         f = newest(os.path.join(src, pm, "**", "*_counter_collection.csv"))
