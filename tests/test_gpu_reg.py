@@ -293,11 +293,16 @@ def test_full_size_registration_properties(dev):
             assert dev.corr_sums(ms, pad, m) == want, f"kernel {kern}"
     dev.corr_padded_force_kernel(-1)
     # The last workgroup to finish sums the partials of all the others, which reach it through agent-scope stores and
-    # loads instead of fences (csrc/corr_finish.h): 200 evaluations at full size must all publish the same bits.
-    first = dev.corr_sums(ms, pad, rot)
-    assert all(dev.corr_sums(ms, pad, rot) == first for _ in range(200))
-    first = dev.corr_sums(ms, ms, rot)
-    assert all(dev.corr_sums(ms, ms, rot) == first for _ in range(50))
+    # loads instead of fences (csrc/corr_finish.h): hundreds of evaluations at full size must all publish the right bits.
+    # Consecutive evaluations alternate between matrices, so a partial left over from the previous evaluation (a stale
+    # read) would change the sum.
+    mats = (rot, ident, rot20)
+    want = [dev.corr_sums(ms, pad, m) for m in mats]
+    for i in range(300):
+        assert dev.corr_sums(ms, pad, mats[i % 3]) == want[i % 3], f"evaluation {i}"
+    want = [dev.corr_sums(ms, ms, m) for m in mats]
+    for i in range(60):
+        assert dev.corr_sums(ms, ms, mats[i % 3]) == want[i % 3], f"evaluation {i} (general kernel)"
     pad.close()
     assert abs(ss2 - ss) <= 1e-12 * ss and abs(st2 - 2.0 * st) <= 1e-9 * abs(st)
     shift = ident.copy()
