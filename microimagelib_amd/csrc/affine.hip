@@ -267,9 +267,7 @@ CorrWorkspace::~CorrWorkspace() {
 }
 
 CorrTail CorrWorkspace::next(size_t nblocks) {
-    // a group of the two-level tail holds nblocks / kCorrCounters partials and one 256-thread workgroup sums it with
-    // 8 loads per thread (corr_finish.h): 131 072 workgroups = 2048 x 2048 x 512 target voxels
-    if (nblocks == 0 || nblocks > (size_t)kCorrCounters * 8 * 256) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    if (nblocks == 0 || nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: volume exceeds launch limits");
     if (partials.size() < 2 * nblocks + 2 * kCorrCounters) partials.alloc(2 * nblocks + 2 * kCorrCounters);
     ticket += 1.0;
     return CorrTail{partials.get(), (int)nblocks, counter.get(), host, ticket};

@@ -33,25 +33,27 @@ __device__ __forceinline__ unsigned corr_count(unsigned *c) {
 }
 
 // Sum of n (ss, st) pairs p[i * stride], q[i * stride] in a fixed order: thread-strided, then waves, then thread 0.
-// All loads of a thread are issued before the first add (n <= 8 * THREADS per call site), so the tail costs one
-// memory round trip, not one per element.  Result valid in thread 0.
+// A thread issues 8 loads per array before the first add, so the tail costs one memory round trip per 8 * THREADS
+// elements, not one per element.  Result valid in thread 0.
 template <int THREADS>
 __device__ __forceinline__ void corr_block_sum(const double *p, const double *q, int n, int stride, double *lds,
                                                double &r0, double &r1) {
     constexpr int WAVES = THREADS / 64;
-    double v0[8], v1[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = (int)threadIdx.x + k * THREADS;
-        const bool ok = i < n;
-        v0[k] = ok ? corr_load_agent(p + (size_t)i * stride) : 0.0;
-        v1[k] = ok ? corr_load_agent(q + (size_t)i * stride) : 0.0;
-    }
     double s0 = 0.0, s1 = 0.0;
+    for (int base = 0; base < n; base += 8 * THREADS) {  // one trip up to 2048 partials per group (512 x 512 x 256: 512)
+        double v0[8], v1[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        s0 += v0[k];
-        s1 += v1[k];
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + (int)threadIdx.x + k * THREADS;
+            const bool ok = i < n;
+            v0[k] = ok ? corr_load_agent(p + (size_t)i * stride) : 0.0;
+            v1[k] = ok ? corr_load_agent(q + (size_t)i * stride) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s0 += v0[k];
+            s1 += v1[k];
+        }
     }
     s0 = corr_wave_sum(s0);
     s1 = corr_wave_sum(s1);
@@ -84,7 +86,7 @@ __device__ __forceinline__ void corr_publish(double a0, double a1, CorrTail t, d
     const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int groups = t.nblocks < kCorrCounters ? t.nblocks : kCorrCounters;
     const int grp = b % groups;
-    const int members = (t.nblocks - grp + groups - 1) / groups;  // <= 8 * THREADS, checked by CorrWorkspace::next
+    const int members = (t.nblocks - grp + groups - 1) / groups;
     double *gsum = t.partials + 2 * (size_t)t.nblocks;             // [2][kCorrCounters]
     if (threadIdx.x == 0) {
         corr_store_agent(t.partials + b, a0);

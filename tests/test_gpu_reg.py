@@ -319,3 +319,19 @@ def test_full_size_registration_properties(dev):
     reg, tmx, rec = dev.reg3d_affine(vol, vol, aff_method=1, it_limit=40)
     assert rec[1] > 0.999999 and rec[3] >= rec[1] - 1e-6
     assert np.allclose(tmx, ident, atol=0.05)
+
+
+def test_cost_tail_sums_many_workgroups(dev):
+    """196 608 workgroups (> 2048 partials per group of the two-level tail, csrc/corr_finish.h) on a 4096 x 4096 x 48
+    volume, which is also beyond the padded kernels' 32-bit offsets: a constant volume under the identity has sums that
+    are exact in float64, N * c * c."""
+    import torch
+    shape = (48, 4096, 4096)
+    c = 0.5
+    vol = torch.full(shape, c, device="cuda")
+    ident = np.eye(3, 4, dtype=np.float32).reshape(12)
+    assert not dev.PaddedSource.eligible(shape, shape)
+    n = float(np.prod(shape))
+    for _ in range(3):
+        ss, st = dev.corr_sums(vol, vol, ident)
+        assert ss == n * c * c and st == n * c * c
