@@ -118,9 +118,24 @@ def test_register_once_apply_to_all_two_ranks(tmp_path):
 
 
 @pytest.mark.timeout(120)
-def test_chained_mode_refuses_to_shard(tmp_path):
+def test_chained_mode_two_ranks_matches_single_rank(tmp_path):
+    """regMode 2: rank 0 walks the matrix chain over all time points and posts each result to the owner, which applies
+    it (regChoice 0); matrices and MIP stack equal the single-rank run."""
     r0, r1 = _run(tmp_path, reg_mode=2)
-    assert "regMode 2" in r0["err"] and "regMode 2" in r1["err"]
+    assert r0["err"] is None and r1["err"] is None
+    # rank 0 registered every time point in order: first with the configured scheme, then chained (regChoice 2 from
+    # the running average)
+    regs = [e for e in r0["log"] if e[1] != 0]
+    assert [e[0] for e in regs] == [3, 4, 5, 6, 7]
+    assert regs[0] == [3, 2, False] and all(e == [t, 2, True] for e, t in zip(regs[1:], [4, 5, 6, 7]))
+    # rank 1 only applied what it was sent
+    assert [e[:2] for e in r1["log"]] == [[4, 0], [6, 0]] and all(e[2] for e in r1["log"])
+    assert sorted(int(t) for t in r0["sunk"]) == [3, 5, 7] and sorted(int(t) for t in r1["sunk"]) == [4, 6]
+    (tmp_path / "single").mkdir()
+    (s0,) = _run(tmp_path / "single", reg_mode=2, world=1)
+    merged = {**r0["sunk"], **r1["sunk"]}
+    assert merged == s0["sunk"]
+    assert r0["stack"] == s0["stack"] == [31.0, 41.0, 51.0, 61.0, 71.0] and r1["stack"] is None
 
 
 def test_fallback_ladder_matches_reference():
