@@ -320,15 +320,17 @@ def main():
         torch.cuda.synchronize()
         reg, tmx, rec = mdev.reg3d_affine(target, source, aff_method=7, ftol=1e-4, it_limit=3000)
         evals, opt_s = float(rec[5]), float(rec[6])
+        launches = float(mdev.reg3d_last_cost_launches())  # evaluations that really passed over both volumes
         result["extra"]["reg3d"] = {
             "workload": "reg3D 12-DOF cascade (affMethod 7), Powell + correlation cost, 512x512x256",
-            "voxels_per_s": round(n_real * evals / opt_s, 1) if opt_s > 0 else None,
+            "voxels_per_s": round(n_real * launches / opt_s, 1) if opt_s > 0 else None,
             "cost_evaluations": int(evals),
+            "cost_kernel_launches": int(launches),
             "evaluations_per_s": round(evals / opt_s, 2) if opt_s > 0 else None,
             "optimisation_s": round(opt_s, 3),
             "zncc_initial": round(float(rec[1]), 5),
             "zncc_final": round(float(rec[3]), 5),
-            "hbm_roofline_frac_per_eval": round(2 * R * evals / opt_s / 1e9 / HBM_PEAK_GBS, 4) if opt_s > 0 else None,
+            "hbm_roofline_frac_per_eval": round(2 * R * launches / opt_s / 1e9 / HBM_PEAK_GBS, 4) if opt_s > 0 else None,
         }
         del reg, source
 

@@ -107,6 +107,9 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
 /* test / profiling aid (process-wide): pin the padded-source kernel -- 0 plain layout + plane reuse, 1 row-pair layout,
  * 2 row-pair layout + plane reuse; -1 (default) chooses per matrix.  Every choice returns the same sums. */
 int mil_corr_padded_force_kernel(int kernel);
+/* cost-kernel launches of this thread's last mil_reg3d_affine (records[5] counts evaluations like the reference; repeats of
+ * a point just visited are answered from the last results, same value, no launch) */
+int mil_reg3d_last_cost_launches(void);
 /* reg3d_affine1, src/api_subfunc.cu:2733-2994, on device-resident volumes of equal size */
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records,

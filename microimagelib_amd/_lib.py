@@ -84,6 +84,7 @@ SIGNATURES = {
     "mil_affine_resample": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, C.c_void_p]),
     "mil_corr_sums": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, c_double_p, C.c_void_p]),
     "mil_padded_source_eligible": (C.c_int, [C.c_int] * 6),
+    "mil_reg3d_last_cost_launches": (C.c_int, []),
     "mil_corr_padded_force_kernel": (C.c_int, [C.c_int]),
     "mil_padded_source_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "mil_padded_source_destroy": (None, [C.c_void_p]),

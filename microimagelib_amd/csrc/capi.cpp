@@ -240,6 +240,7 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
         return 0;
     });
 }
+int mil_reg3d_last_cost_launches(void) { return reg3d_last_cost_launches(); }
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records, void *stream) {
     return guarded("mil_reg3d_affine", [&] {

@@ -12,6 +12,9 @@
 
 namespace mil {
 
+static thread_local int g_last_cost_launches = 0;
+int reg3d_last_cost_launches() { return g_last_cost_launches; }
+
 // ---------------------------------------------------------------------------
 // matrix parameterisations
 // ---------------------------------------------------------------------------
@@ -447,18 +450,38 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
         src_ms.release();
     }
 
-    int evals = 0;
+    int evals = 0, launches = 0;
     bool dof9 = false;
     int dof_num = 12;
+    // Powell re-evaluates points it has just visited (every line minimisation starts by evaluating its own starting
+    // point, src/api_powell.c:291-293 / mnbrak).  The cost is a deterministic function of the 12 matrix floats, so a
+    // repeat is answered from the last few results instead of another pass over both volumes: same value, same
+    // evaluation count, same trajectory.
+    struct Memo {
+        float m[12];
+        float value;
+    };
+    constexpr int kMemo = 4;
+    Memo memo[kMemo];
+    int memo_n = 0, memo_next = 0;
+    static const bool memo_off = getenv("MIL_REG_NOMEMO") && getenv("MIL_REG_NOMEMO")[0] == '1';
     CostFn cost = [&](const float *x) -> float {  // costfunc :2377-2388 + corrfunc :954-988
         if (dof9) dof9tomatrix(aff.m, x, dof_num);
         else p2matrix(aff.m, x);
+        ++evals;
+        if (!memo_off)
+            for (int i = 0; i < memo_n; ++i)
+                if (std::memcmp(memo[i].m, aff.m, sizeof aff.m) == 0) return memo[i].value;
+        ++launches;
         double ss = 0, st = 0;
         if (padded) k::corr_sums_padded_sync(tgt_ms.get(), src_pad, dims, aff, corr, stream, &ss, &st);
         else k::corr_sums_sync(tgt_ms.get(), src_ms.get(), dims, dims, aff, corr, stream, &ss, &st);
-        ++evals;
         const double root = std::sqrt(ss);
         const float zncc = (root == 0) ? -2.0f : (float)(st / root) / sd_t;
+        std::memcpy(memo[memo_next].m, aff.m, sizeof aff.m);
+        memo[memo_next].value = -zncc;
+        memo_next = (memo_next + 1) % kMemo;
+        if (memo_n < kMemo) ++memo_n;
         return -zncc;
     };
 
@@ -468,6 +491,7 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
     records[4] = 0.f;
     if (verbose) printf("\t... initial cross correlation value: %f;\n", records[1]);
     evals = 0;
+    launches = 0;
 
     PowellResult r;
     auto stage9 = [&](int n_dof, float tol) {
@@ -516,9 +540,11 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
     records[3] = -r.fret;
     records[5] = (float)evals;
     records[6] = (float)seconds_since(t_opt);
+    g_last_cost_launches = launches;
     if (verbose) {
         printf("\t... optimized cross correlation value: %f;\n", records[3]);
         printf("\t... total sub iteration number: %d;\n", evals);
+        if (launches != evals) printf("\t... (%d of them answered from the last results)\n", evals - launches);
         printf("\t... time cost for all iterations: %f s;\n", records[6]);
     }
     // final resample of the RAW source (:2974-2977)

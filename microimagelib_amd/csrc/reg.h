@@ -24,6 +24,9 @@ struct RegOptions {
 // reg3d_affine1, reference src/api_subfunc.cu:2733-2994.  d_img1 = target, d_img2 = source,
 // both `dims`; d_reg receives the resampled source.  records: >= 8 floats ([1..7] written).
 // Throws Error; returns 0.
+// Cost-kernel launches of this thread's last reg3d_affine_device optimisation; records[5] counts cost EVALUATIONS as the
+// reference does, a few per cent of which repeat a point just visited and are answered without a launch.
+int reg3d_last_cost_launches();
 int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, Dims dims,
                         int aff_method, bool flag_tmx, float ftol, int it_limit, bool verbose, float *records,
                         hipStream_t stream, const RegOptions &opt = RegOptions());

@@ -160,6 +160,12 @@ def corr_sums(target: torch.Tensor, src, m12, stream=None):
     return out[0], out[1]
 
 
+def reg3d_last_cost_launches() -> int:
+    """Cost-kernel launches of the last reg3d_affine on this thread (records[5] counts evaluations; repeats of a point
+    just visited cost no launch)."""
+    return int(_lib.load().mil_reg3d_last_cost_launches())
+
+
 def reg3d_affine(target: torch.Tensor, source: torch.Tensor, aff_method=6, i_tmx=None, flag_tmx=False, ftol=1e-4,
                  it_limit=3000, verbose=False, stream=None):
     """reg3d_affine1 on device-resident volumes.  Returns (registered, tmx[12], records[11])."""
