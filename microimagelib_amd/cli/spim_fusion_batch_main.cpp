@@ -3,11 +3,17 @@
 // Same 34 (or 36) positional arguments, folder layout, matrix files and log as the reference tool
 // (src/spim_fusion_batch.cpp:58-113, 135-190, 262-296, 613-966) -- "set same with the ImageJ diSPIMFusion plugin".
 // One process, one GPU, like the reference; the multi-GPU driver that shards time points is microimagelib_amd/batch.py.
+// Unlike the reference the file I/O does not sit in the GPU's way: the next time point's two stacks are read (and
+// converted to float) on a helper thread while this one is registered and deconvolved, and the deconvolved stack is
+// written behind while the projections and the next time point proceed -- at 512 x 512 x 256 the TIFF work is as long
+// as the GPU work.  Same files, same order of results, same log.
 #include <sys/stat.h>
 
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <future>
+#include <utility>
 
 #include "cli_common.h"
 
@@ -177,6 +183,14 @@ int main(int argc, char **argv) {
     log("\n=== spimFusionBatch: images %d .. %d (step %d), size %lld x %lld x %lld, regMode %d, %d decon iterations\n",
         n_start, n_end, n_step, sx, sy, sz, reg_mode, iters);
 
+    // read-ahead / write-behind
+    typedef std::pair<cli::Volume, cli::Volume> Pair;
+    auto load_pair = [&](int n) { return Pair(cli::load_tiff(name_of(dir1, base1, n)), cli::load_tiff(name_of(dir2, base2, n))); };
+    std::future<Pair> ahead;
+    int ahead_n = 0;
+    std::future<void> behind;
+    std::vector<float> decon_out(total);
+
     bool first = true;
     for (int n = n_start; n <= n_end; n += n_step) {
         int reg_choice_now = reg_choice;
@@ -186,28 +200,52 @@ int main(int argc, char **argv) {
         const auto t0 = std::chrono::steady_clock::now();
 
         // ---- preprocessing (:666-711)
-        cli::Volume a_in = cli::load_tiff(name_of(dir1, base1, n)), b_in = cli::load_tiff(name_of(dir2, base2, n));
+        Pair in = (ahead.valid() && ahead_n == n) ? ahead.get() : load_pair(n);
+        if (ahead.valid()) ahead.wait();  // a read-ahead that is not wanted after all (regMode 1 jumps back)
+        {   // next time point: only when both files are there -- a missing file must stop the batch where the
+            // reference stops it, after this time point's results are written
+            const int nn = n + n_step;
+            const bool test_pass = reg_mode == 1 && first;
+            if (!test_pass && nn <= n_end && fexists(const_cast<char *>(name_of(dir1, base1, nn).c_str())) &&
+                fexists(const_cast<char *>(name_of(dir2, base2, nn).c_str()))) {
+                ahead_n = nn;
+                ahead = std::async(std::launch::async, load_pair, nn);
+            }
+        }
+        cli::Volume &a_in = in.first, &b_in = in.second;
         if (a_in.size[0] != in1[0] || a_in.size[1] != in1[1] || a_in.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); return 1; }
         if (b_in.size[0] != in2[0] || b_in.size[1] != in2[1] || b_in.size[2] != in2[2]) { printf("\t Input image 2 size does not match !!!\n"); return 1; }
-        cli::Volume a = a_in;
-        if (a.size[0] != size[0] || a.size[1] != size[1] || a.size[2] != size[2]) {
-            a.data.resize(total);
-            for (int i = 0; i < 3; ++i) a.size[i] = size[i];
-            (void)imresize3d(a.data.data(), a_in.data.data(), sx, sy, sz, a_in.size[0], a_in.size[1], a_in.size[2], device);
+        // no copies: a stack that needs no resampling / rotation is used where it was read
+        cli::Volume a_res, b_rot_own, b_res;
+        cli::Volume *a_ptr = &a_in;
+        if (a_in.size[0] != size[0] || a_in.size[1] != size[1] || a_in.size[2] != size[2]) {
+            a_res.bits = a_in.bits;
+            a_res.data.resize(total);
+            for (int i = 0; i < 3; ++i) a_res.size[i] = size[i];
+            (void)imresize3d(a_res.data.data(), a_in.data.data(), sx, sy, sz, a_in.size[0], a_in.size[1], a_in.size[2], device);
+            a_ptr = &a_res;
         }
-        cli::Volume b_rot = b_in;
-        if (op_choice != 0) (void)imoperation3D(b_rot.data.data(), b_rot.size, b_in.data.data(), b_in.size, op_choice, device);
-        cli::Volume b = b_rot;
-        if (b.size[0] != size2[0] || b.size[1] != size2[1] || b.size[2] != size2[2]) {
-            b.data.resize((size_t)size2[0] * size2[1] * size2[2]);
-            for (int i = 0; i < 3; ++i) b.size[i] = size2[i];
-            (void)imresize3d(b.data.data(), b_rot.data.data(), size2[0], size2[1], size2[2], b_rot.size[0], b_rot.size[1],
+        cli::Volume *b_rot_ptr = &b_in;
+        if (op_choice != 0) {
+            b_rot_own.bits = b_in.bits;
+            b_rot_own.data.resize(b_in.count());
+            (void)imoperation3D(b_rot_own.data.data(), b_rot_own.size, b_in.data.data(), b_in.size, op_choice, device);
+            b_rot_ptr = &b_rot_own;
+        }
+        cli::Volume &b_rot = *b_rot_ptr;
+        cli::Volume *b_ptr = &b_rot;
+        if (b_rot.size[0] != size2[0] || b_rot.size[1] != size2[1] || b_rot.size[2] != size2[2]) {
+            b_res.bits = b_rot.bits;
+            b_res.data.resize((size_t)size2[0] * size2[1] * size2[2]);
+            for (int i = 0; i < 3; ++i) b_res.size[i] = size2[i];
+            (void)imresize3d(b_res.data.data(), b_rot.data.data(), size2[0], size2[1], size2[2], b_rot.size[0], b_rot.size[1],
                              b_rot.size[2], device);
+            b_ptr = &b_res;
         }
+        cli::Volume &a = *a_ptr, &b = *b_ptr;
         const auto t1 = std::chrono::steady_clock::now();
 
         // ---- registration with the reference's fall-back ladder (:714-843)
-        std::fill(b_reg.begin(), b_reg.end(), 0.f);
         if (have_itmx) std::memcpy(initial_tmx, tmx, sizeof tmx);
         auto run = [&](int choice, bool use_input) {
             return reg3d(b_reg.data(), tmx, a.data.data(), b.data.data(), a.size, b.size, choice, aff_method, use_input, ftol,
@@ -270,18 +308,27 @@ int main(int argc, char **argv) {
         const auto t2 = std::chrono::steady_clock::now();
 
         // ---- joint deconvolution (:874-911)
-        std::fill(decon.begin(), decon.end(), 0.f);
         (void)decon_dualview(decon.data(), a.data.data(), b_reg.data(), size, psf1.data.data(), psf2.data.data(), psf1.size, false,
                              iters, device, -1, true, decon_records, unmatch, bp1.data.data(), bp2.data.data());
         log("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
             decon_records[5]);
-        writetifstack(const_cast<char *>((decon_dir + "Decon_" + ns + ".tif").c_str()), decon.data(), size, out_bits);
+        if (behind.valid()) behind.get();  // the previous stack has left decon_out
+        decon_out.swap(decon);             // projections below read decon_out; decon is scratch again
+        {
+            const std::string path = decon_dir + "Decon_" + ns + ".tif";
+            const float *data = decon_out.data();
+            unsigned int wsize[3] = {size[0], size[1], size[2]};
+            const unsigned short bits = out_bits;
+            behind = std::async(std::launch::async, [path, data, wsize, bits]() mutable {
+                writetifstack(const_cast<char *>(path.c_str()), const_cast<float *>(data), wsize, bits);
+            });
+        }
         const auto t3 = std::chrono::steady_clock::now();
 
         // ---- projections (:913-943)
         if (save_zproj || save_xproj || save_yproj) {
             unsigned int mp_size[6];
-            (void)mp2dgpu(mp.data(), mp_size, decon.data(), size, save_zproj, save_xproj, save_yproj);
+            (void)mp2dgpu(mp.data(), mp_size, decon_out.data(), size, save_zproj, save_xproj, save_yproj);
             unsigned int s2[3] = {0, 0, 1};
             if (save_zproj) { s2[0] = mp_size[0]; s2[1] = mp_size[1]; writetifstack(const_cast<char *>((mp_xy + "MP_XY_" + ns + ".tif").c_str()), mp.data(), s2, out_bits); }
             if (save_xproj) { s2[0] = mp_size[2]; s2[1] = mp_size[3]; writetifstack(const_cast<char *>((mp_yz + "MP_YZ_" + ns + ".tif").c_str()), mp.data() + sx * sy, s2, out_bits); }
@@ -293,7 +340,7 @@ int main(int argc, char **argv) {
             const long long rot = (long long)std::llround(std::sqrt(axis == 1 ? (double)(sy * sy + sz * sz) : (double)(sx * sx + sz * sz)));
             std::vector<float> mp3d((size_t)((axis == 1 ? sx : sy) * rot * project_num));
             unsigned int s3[3];
-            (void)mip3dgpu(mp3d.data(), s3, decon.data(), size, axis, project_num);
+            (void)mip3dgpu(mp3d.data(), s3, decon_out.data(), size, axis, project_num);
             writetifstack(const_cast<char *>(((axis == 1 ? mp_3dx + "MP_3D_Xaxis_" : mp_3dy + "MP_3D_Yaxis_") + ns + ".tif").c_str()),
                           mp3d.data(), s3, out_bits);
         }
@@ -301,6 +348,7 @@ int main(int argc, char **argv) {
         log("\tTime cost: preprocessing %2.3f s, registration %2.3f s, deconvolution %2.3f s, projections %2.3f s\n", sec(t0, t1),
             sec(t1, t2), sec(t2, t3), sec(t3, t4));
     }
+    if (behind.valid()) behind.get();
     log("\n=== Batch processing completed, whole time cost: %2.3f s\n", sec(t_batch, std::chrono::steady_clock::now()));
     return 0;
 }

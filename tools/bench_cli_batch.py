@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the spimFusionBatch command-line tool on TIFF files, 512x512x256, 16-bit in / 16-bit out:
+our main (microimagelib_amd/cli, read-ahead + write-behind) against the reference's own main (oracle/_ref/cli,
+strictly sequential I/O), both on the same libapi.so.
+
+    python tools/bench_cli_batch.py [--time-points 4] [--reg-mode 2] [--workdir /tmp/mil_cli_batch]
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--time-points", type=int, default=4)
+    ap.add_argument("--reg-mode", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--workdir", default="/tmp/mil_cli_batch")
+    args = ap.parse_args()
+
+    import torch
+    import bench
+    from microimagelib_amd import api, device as mdev
+
+    w = args.workdir
+    shutil.rmtree(w, ignore_errors=True)
+    os.makedirs(w + "/SPIMA")
+    os.makedirs(w + "/SPIMB")
+    sig_a, sig_b = (6.0, 2.5, 2.5), (2.5, 2.5, 6.0)
+    api.writetifstack(w + "/pa.tif", bench.gaussian_psf(bench.PSF_SHAPE, sig_a), 32)
+    api.writetifstack(w + "/pb.tif", bench.gaussian_psf(bench.PSF_SHAPE, sig_b), 32)
+    base_a = bench.synth_volume(torch, bench.SHAPE, sig_a, seed=7)
+    c, s = np.cos(np.deg2rad(2.0)), np.sin(np.deg2rad(2.0))
+    lin = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+    centre = np.array([256.0, 256.0, 128.0])
+    known = np.concatenate([lin, (centre - lin @ centre + np.array([3.0, -2.0, 1.0]))[:, None]], axis=1).astype(np.float32)
+    base_b = mdev.affine_resample(bench.synth_volume(torch, bench.SHAPE, sig_b, seed=7), known.reshape(12), bench.SHAPE)
+    for t in range(args.time_points):
+        g = torch.Generator(device="cuda").manual_seed(1000 + t)
+        for name, base in (("SPIMA", base_a), ("SPIMB", base_b)):
+            vol = (base + torch.randn(base.shape, device="cuda", generator=g) * 3.0).clamp_(min=0)
+            api.writetifstack(f"{w}/{name}/{name}_{t}.tif", vol.cpu().numpy(), 16)
+    del base_a, base_b
+    torch.cuda.empty_cache()
+
+    def cli_args(out):
+        return [out + "/", w + "/SPIMA/", w + "/SPIMB/", "SPIMA_", "SPIMB_", "0", str(args.time_points - 1), "1", "0",
+                "1", "1", "1", "1", "1", "1", str(args.reg_mode), "0", "0", "none", "0.0001", "3000", "0", "0",
+                w + "/pa.tif", w + "/pb.tif", str(args.iters), "0", "0", "1", "0", "0", "16", "0", "0"]
+
+    res = {}
+    for name, exe in (("reference main, sequential I/O", os.path.join(ROOT, "oracle", "_ref", "cli", "spimFusionBatch")),
+                      ("our main, read-ahead + write-behind", os.path.join(ROOT, "microimagelib_amd", "bin", "spimFusionBatch"))):
+        if not os.path.exists(exe):
+            res[name] = None
+            continue
+        out = w + "/out_" + ("ref" if "reference" in name else "ours")
+        t0 = time.perf_counter()
+        r = subprocess.run([exe] + cli_args(out), capture_output=True, text=True, timeout=1800)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise SystemExit(r.stdout[-1500:] + r.stderr[-1500:])
+        res[name] = {"seconds": round(dt, 3), "time_points_per_s": round(args.time_points / dt, 3)}
+    same = None
+    if all(res.values()):
+        same = all(np.array_equal(api.readtifstack(f"{w}/out_ref/Decon/Decon_{t}.tif"),
+                                  api.readtifstack(f"{w}/out_ours/Decon/Decon_{t}.tif")) for t in range(args.time_points))
+    print(json.dumps({"workload": f"spimFusionBatch CLI, {args.time_points} time points 512x512x256, 16-bit TIFF in/out, "
+                                  f"regMode {args.reg_mode}, {args.iters} RL iterations, process start to exit",
+                      "results": res, "identical_decon_stacks": same}))
+    shutil.rmtree(w, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
