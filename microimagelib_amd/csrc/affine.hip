@@ -9,16 +9,12 @@
 // Interpolation weights are exact float32 (CUDA's texture unit quantises them to 8
 // fractional bits; see DESIGN.md "Registration numerics").
 //
-// Per target voxel: one coalesced target read and four 8-byte source gathers whose footprint,
-// for the near-identity matrices registration visits, is a sheared box only slightly larger
-// than the target tile -- the gathers hit L1/L2 and HBM traffic stays ~ (target + source) bytes.
-// Measured limits (rocprofv3 PMC at 512x512x256, profiles/r01_final/reg_cost_kernel.json): before the plane cache the
-// cost kernel issued 104 VALU and 5 vector-memory instructions per voxel-wave; the texture-address path was busy 73 % (a quad of lanes
-// per cycle) and VALU issue ~50 %, so it is co-limited by gather issue and arithmetic, not by HBM
-// (29 % of the 2R roofline).  Two LDS-staged variants (a 32x16x16 slab with an exact bounding box,
-// and a z-marching ring of source planes with an 8-deep register prefetch FIFO) were built and
-// measured SLOWER (0.36 and 0.43 ms per evaluation against 0.215 ms): the staging and ring
-// bookkeeping add more VALU work than the gathers they remove.  They live in the git history only.
+// corr_kernel here is the GENERAL cost kernel (any volume size, 2-D images, the raw C-ABI entry mil_corr_sums): per target
+// voxel one coalesced target read and four 8-byte source gathers with clamped indices, two of them usually skipped by
+// plane reuse.  The 3-D registration itself evaluates the border-padded kernels of corr_padded.hip, which return the
+// same sums bit for bit with about half the instructions; DESIGN.md section 4 has the measurements (what bounds these
+// kernels is the texture-address path and VALU issue, not HBM) and the three LDS-staged variants that were built,
+// measured slower and dropped.  Every cost kernel ends in corr_publish (corr_finish.h): one launch per evaluation.
 #include "corr_finish.h"
 #include "kernels.h"
 
