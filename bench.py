@@ -41,7 +41,7 @@ def synth_volume(torch, shape, psf, seed):
     n_blobs = 200
     idx = [torch.randint(0, s, (n_blobs,), device="cuda", generator=g) for s in shape]
     amp = torch.rand(n_blobs, device="cuda", generator=g) * 1800 + 200
-    pts[idx[0], idx[1], idx[2]] = amp * 60
+    pts[idx[0], idx[1], idx[2]] = amp * 425.0  # unit-sum sigma-3 kernel peaks at 1/425: blob peak = amp (200..2000) over background 100
     # blob shape: isotropic Gaussian sigma 3; then the view PSF
     def gauss_kernel(sig):
         ax = [torch.arange(s, device="cuda", dtype=torch.float32) for s in shape]
@@ -332,7 +332,17 @@ def main():
             "zncc_final": round(float(rec[3]), 5),
             "hbm_roofline_frac_per_eval": round(2 * R * launches / opt_s / 1e9 / HBM_PEAK_GBS, 4) if opt_s > 0 else None,
         }
-        del reg, source
+        # the same pair through the direct 12-DOF search (affMethod 5), SURVEY.md section 8(d)
+        reg5, tmx5, rec5 = mdev.reg3d_affine(target, source, aff_method=5, ftol=1e-4, it_limit=3000)
+        ev5, s5, l5 = float(rec5[5]), float(rec5[6]), float(mdev.reg3d_last_cost_launches())
+        result["extra"]["reg3d_direct_12dof"] = {
+            "workload": "reg3D direct 12-DOF (affMethod 5), same volumes",
+            "voxels_per_s": round(n_real * l5 / s5, 1) if s5 > 0 else None,
+            "cost_evaluations": int(ev5), "cost_kernel_launches": int(l5),
+            "evaluations_per_s": round(ev5 / s5, 2) if s5 > 0 else None, "optimisation_s": round(s5, 3),
+            "zncc_initial": round(float(rec5[1]), 5), "zncc_final": round(float(rec5[3]), 5),
+        }
+        del reg, reg5, source
 
     if world == 1 and not args.no_extra:
         # the reference's own boundary: host pointers in / out (H2D, OTF preparation, RL loop, D2H inside the call);
