@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--cpu-fft-threads", type=int, default=16,
                     help="second CPU figure with the FFTs threaded (a 1-GPU box's share of host cores); 1 = skip")
+    # functional test of the N > 1 path on a one-GPU box: all ranks on cuda:0, collectives over gloo (never a measurement)
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["auto", "rocfft", "fused"], default="auto",
                     help="transform backend of the RL engine (auto = fused LDS-tiled kernels on power-of-two boxes)")
     args = ap.parse_args()
@@ -123,11 +126,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (got WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     distributed = world > 1
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the (tiny) collective payloads live
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from microimagelib_amd import _lib, device as mdev
     lib = _lib.load()
@@ -180,7 +189,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dom_ms, dom_n = eng.timer_read(dom_timer)
@@ -201,7 +210,7 @@ def main():
         eng.timer_enable(w, False)
 
     # ---- gather of the MIP stack (the only inter-GPU exchange of the batch) ------------
-    mip = mdev.max_projection(E, 1)  # XY MIP, 512x512 float32
+    mip = mdev.max_projection(E, 1).to(coll_dev)  # XY MIP, 512x512 float32
     mip_checksum = float(mip.double().sum().item())
     if distributed:
         stack = [torch.empty_like(mip) for _ in range(world)] if rank == 0 else None
