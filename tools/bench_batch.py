@@ -26,7 +26,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time-points", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--reg-mode", type=int, default=3, choices=[0, 1, 3])
+    ap.add_argument("--reg-mode", type=int, default=3, choices=[0, 1, 2, 3])
+    # functional test of the multi-rank path on a one-GPU box: all ranks on cuda:0, collectives over gloo
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--shape", type=int, nargs=3, default=[256, 512, 512], metavar=("NZ", "NY", "NX"))
     ap.add_argument("--host", action="store_true", help="views in pinned host memory, result copied back")
     args = ap.parse_args()
@@ -41,10 +44,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench_batch.py needs a GPU")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     shape = tuple(args.shape)
     sig_a, sig_b = (6.0, 2.5, 2.5), (2.5, 2.5, 6.0)
@@ -111,7 +120,7 @@ def main():
                                      i_tmx=known if args.reg_mode == 0 else None)
     # warm-up: one time point per rank (plans, OTFs, clocks), not timed
     batch.run_sharded(tps[:world], load_pair, fuse_pair, policy(), reg_fn, pipe.check_fn, (shape[1], shape[2]),
-                      sink=sink, device="cuda")
+                      sink=sink, device=coll_dev)
     for k in split:
         split[k] = 0.0
     evals.clear()
@@ -120,13 +129,13 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     stack = batch.run_sharded(tps, load_pair, fuse_pair, policy(), reg_fn, pipe.check_fn, (shape[1], shape[2]),
-                              sink=sink, device="cuda")
+                              sink=sink, device=coll_dev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
