@@ -107,6 +107,8 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
 /* test / profiling aid (process-wide): pin the padded-source kernel -- 0 plain layout + plane reuse, 1 row-pair layout,
  * 2 row-pair layout + plane reuse; -1 (default) chooses per matrix.  Every choice returns the same sums. */
 int mil_corr_padded_force_kernel(int kernel);
+/* host logic only (no GPU needed): which of the three the per-matrix choice takes for m12 */
+int mil_corr_padded_pick_kernel(const float *m12);
 /* cost-kernel launches of this thread's last mil_reg3d_affine (records[5] counts evaluations like the reference; repeats of
  * a point just visited are answered from the last results, same value, no launch) */
 int mil_reg3d_last_cost_launches(void);

@@ -221,6 +221,11 @@ int mil_padded_source_create(mil_padded_source **out, const float *d_src, int sx
     });
 }
 void mil_padded_source_destroy(mil_padded_source *p) { delete p; }
+int mil_corr_padded_pick_kernel(const float *m12) {
+    k::Affine12 m;
+    std::memcpy(m.m, m12, sizeof m.m);
+    return k::corr_padded_pick_kernel(m);
+}
 int mil_corr_padded_force_kernel(int kernel) {
     k::corr_padded_force_kernel(kernel);
     return 0;

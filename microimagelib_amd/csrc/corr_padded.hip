@@ -369,6 +369,14 @@ int pick_kernel(const float *m, bool has_pairs) {
 
 void corr_padded_force_kernel(int kernel) { g_forced_kernel = kernel; }
 
+int corr_padded_pick_kernel(const Affine12 &m) {
+    const int forced = g_forced_kernel;
+    g_forced_kernel = -1;
+    const int k = pick_kernel(m.m, true);
+    g_forced_kernel = forced;
+    return k;
+}
+
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
                             hipStream_t s) {
     if (!PaddedSource::eligible(t, src.dims) || !src.data.get())

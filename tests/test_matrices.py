@@ -105,3 +105,25 @@ def test_fft_digit_reversal_tables():
         assert np.array_equal(got, model(n))
         assert np.array_equal(np.sort(got), np.arange(n))
     assert lib.mil_fft_digit_reversal(0, (C.c_ushort * 4)()) == -1
+
+
+def test_cost_kernel_choice_per_matrix(lib):
+    """pick_kernel (csrc/corr_padded.hip): which padded-source cost kernel a matrix gets -- host logic, no GPU.
+    0 plain layout + plane reuse, 2 row pairs + plane reuse, 1 row pairs without reuse."""
+    def rot_y(deg, scale=1.0):
+        c, s = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
+        m = np.array([c, 0, -s, 0, 0, 1, 0, 0, s, 0, c, 0], dtype=np.float64) * scale
+        m[[3, 7, 11]] = (4.0, -2.0, 1.0)
+        return m.astype(f32)
+
+    def pick(m):
+        return lib.mil_corr_padded_pick_kernel(fp(np.ascontiguousarray(m, dtype=f32)))
+
+    ident = np.eye(3, 4, dtype=f32).reshape(12)
+    assert pick(ident) == 0                      # every lane reuses its plane at every step
+    assert pick(rot_y(0.0, 1.05)) == 0           # pure scale: all lanes of a wave cross planes together
+    assert pick(rot_y(1.0)) == 0 and pick(rot_y(2.0)) == 0
+    assert pick(rot_y(3.0, 1.02)) == 2           # a few degrees AND a few per cent: lanes drift out of step
+    assert pick(rot_y(5.0)) == 2 and pick(rot_y(10.0)) == 2
+    assert pick(rot_y(20.0)) == 1 and pick(rot_y(45.0)) == 1
+    assert pick(np.full(12, np.nan, dtype=f32)) == 0   # NaN never satisfies a threshold; any kernel rejects every voxel
