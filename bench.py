@@ -240,6 +240,9 @@ def main():
                 "rocfft_execute (library 3-D real transform, 3-4 kernels)": (fft_ms, fft_n, R + C),
             }
             iter_bytes = 4 * (R + C) + 2 * 3 * C + 3 * R + 3 * R
+        upd_key = [k for k in fam if k.startswith(("x_update", "rl_update"))][0]
+        upd_frac = (round(fam[upd_key][2] / (upd_ms / upd_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    if upd_n and upd_ms > 0 else None)
         dom = [k for k in fam if k.startswith("y_pass" if fused else "cmul_otf")][0]
         dom_bytes = fam[dom][2]
         dom_avg_ms = dom_ms / max(dom_n, 1)  # measured inside the timed region
@@ -298,6 +301,9 @@ def main():
                                                      / HBM_PEAK_GBS, 4),
                 "iteration_bytes_this_backend_minimum": iter_bytes,
                 "mip_checksum": mip_checksum,
+                # north_star: ">= 60 % of HBM-read roofline on the RL element-wise update" -- the kernel that carries it
+                # (fused backend: x^-1 . E = max(E*T, eps) . x on 2C + 2R bytes; rocFFT backend: the 3R update kernel)
+                "rl_update_kernel_hbm_frac": upd_frac,
             },
         }
 
