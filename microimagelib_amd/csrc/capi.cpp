@@ -19,6 +19,49 @@ struct mil_decon {
 namespace {
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline Dims dims3(int x, int y, int z) { return Dims{x, y, z}; }
+
+// The registration entry points poll a pinned result slot between launches, so they do not run on the null stream
+// (every launch there would also serialise against the caller's other streams).  A caller that passes stream 0 --
+// torch's default stream -- gets a private non-blocking stream that is ORDERED after everything already queued on the
+// null stream (pending H2D copies, the kernels that produced the inputs), and the null stream is ordered after the
+// private one on the way out, so the call behaves as if it had run on stream 0.
+class WorkStream {
+public:
+    explicit WorkStream(hipStream_t given) : s_(given) {
+        if (s_) return;
+        MIL_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+        own_ = true;
+        if (hipEventCreateWithFlags(&ev_, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(ev_, nullptr) != hipSuccess || hipStreamWaitEvent(s_, ev_, 0) != hipSuccess) {
+            release();
+            throw Error(-1, "WorkStream: cannot order the private stream after the null stream");
+        }
+    }
+    WorkStream(const WorkStream &) = delete;
+    WorkStream &operator=(const WorkStream &) = delete;
+    ~WorkStream() { release(); }
+    hipStream_t get() const { return s_; }
+    void finish() {
+        if (!own_) return;
+        MIL_HIP(hipEventRecord(ev_, s_));
+        MIL_HIP(hipStreamWaitEvent(nullptr, ev_, 0));
+    }
+
+private:
+    void release() {
+        if (ev_) (void)hipEventDestroy(ev_);
+        if (own_ && s_) {
+            (void)hipStreamSynchronize(s_);
+            (void)hipStreamDestroy(s_);
+        }
+        ev_ = nullptr;
+        s_ = nullptr;
+        own_ = false;
+    }
+    hipStream_t s_ = nullptr;
+    hipEvent_t ev_ = nullptr;
+    bool own_ = false;
+};
 }  // namespace
 
 extern "C" {
@@ -249,40 +292,19 @@ int mil_reg3d_last_cost_launches(void) { return reg3d_last_cost_launches(); }
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records, void *stream) {
     return guarded("mil_reg3d_affine", [&] {
-        hipStream_t s = as_stream(stream);
-        bool own = false;
-        if (!s) {
-            MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            own = true;
-        }
-        int rc;
-        try {
-            rc = reg3d_affine_device(d_reg, iTmx, d_img1, d_img2, dims3(nx, ny, nz), affMethod, flagTmx != 0, FTOL,
-                                     itLimit, verbose != 0, records, s);
-        } catch (...) {
-            if (own) (void)hipStreamDestroy(s);
-            throw;
-        }
-        if (own) (void)hipStreamDestroy(s);
+        WorkStream ws(as_stream(stream));
+        const int rc = reg3d_affine_device(d_reg, iTmx, d_img1, d_img2, dims3(nx, ny, nz), affMethod, flagTmx != 0,
+                                           FTOL, itLimit, verbose != 0, records, ws.get());
+        ws.finish();
         return rc;
     });
 }
 
 int mil_reg3d_mip_shift(float *shift3, const float *d_img1, const float *d_img2, int nx, int ny, int nz, void *stream) {
     return guarded("mil_reg3d_mip_shift", [&] {
-        hipStream_t s = as_stream(stream);
-        bool own = false;
-        if (!s) {
-            MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            own = true;
-        }
-        try {
-            mip_shift_search(shift3, d_img1, d_img2, dims3(nx, ny, nz), s);
-        } catch (...) {
-            if (own) (void)hipStreamDestroy(s);
-            throw;
-        }
-        if (own) (void)hipStreamDestroy(s);
+        WorkStream ws(as_stream(stream));
+        mip_shift_search(shift3, d_img1, d_img2, dims3(nx, ny, nz), ws.get());
+        ws.finish();
         return 0;
     });
 }
@@ -290,19 +312,9 @@ int mil_reg3d_mip_shift(float *shift3, const float *d_img1, const float *d_img2,
 int mil_reg3d_phasor_shift(long long *shift3, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                            void *stream) {
     return guarded("mil_reg3d_phasor_shift", [&] {
-        hipStream_t s = as_stream(stream);
-        bool own = false;
-        if (!s) {
-            MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            own = true;
-        }
-        try {
-            phasor_shift(shift3, d_img1, d_img2, dims3(nx, ny, nz), s);
-        } catch (...) {
-            if (own) (void)hipStreamDestroy(s);
-            throw;
-        }
-        if (own) (void)hipStreamDestroy(s);
+        WorkStream ws(as_stream(stream));
+        phasor_shift(shift3, d_img1, d_img2, dims3(nx, ny, nz), ws.get());
+        ws.finish();
         return 0;
     });
 }

@@ -226,10 +226,21 @@ class DeconEngine:
         self.natural_spectrum_shape = (nz, ny, nx // 2 + 1)
         self.spectrum_count = int(self._lib.mil_decon_spectrum_count(h))  # opaque, backend-private layout
 
-    def _enter(self):
+    def _enter(self, *tensors):
+        """Order the engine's stream after torch's current stream (the producer of the operands) and tell the caching
+        allocator that `tensors` are in use on the engine's stream, so that a temporary freed right after the call is
+        not handed out again while the engine still reads or writes it."""
         cur = torch.cuda.current_stream()
         if cur.cuda_stream != self.stream.cuda_stream:
             self.stream.wait_stream(cur)
+            for t in tensors:
+                t.record_stream(self.stream)
+
+    def _leave(self):
+        """Order torch's current stream after the engine's: results can be consumed by torch ops without `sync()`."""
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -245,42 +256,49 @@ class DeconEngine:
     def gen_otf(self, psf: torch.Tensor, flip=False) -> torch.Tensor:
         otf = torch.empty(self.spectrum_count, dtype=torch.complex64, device=psf.device)
         px, py, pz = _dims(psf)
-        self._enter()
+        self._enter(otf, psf)
         _check(self._lib.mil_decon_gen_otf(self._h, _ptr(otf), _ptr(psf), px, py, pz, int(flip)), "mil_decon_gen_otf")
+        self._leave()
         return otf
 
     def otf_to_natural(self, otf: torch.Tensor) -> torch.Tensor:
         """Engine-private OTF -> [nz][ny][nx/2+1] complex64 (numpy rfftn order)."""
         nat = torch.empty(self.natural_spectrum_shape, dtype=torch.complex64, device=otf.device)
-        self._enter()
+        self._enter(nat, otf)
         _check(self._lib.mil_decon_otf_to_natural(self._h, _ptr(nat), _ptr(otf)), "mil_decon_otf_to_natural")
+        self._leave()
         return nat
 
     def convolve(self, vol: torch.Tensor, otf: torch.Tensor) -> torch.Tensor:
         """Unnormalised circular convolution C2R(R2C(vol) * otf)."""
         out = torch.empty_like(vol)
-        self._enter()
+        self._enter(out, vol, otf)
         _check(self._lib.mil_decon_convolve(self._h, _ptr(out), _ptr(vol), _ptr(otf)), "mil_decon_convolve")
+        self._leave()
         return out
 
     def init_single(self, A, E, const_init=False):
-        self._enter()
+        self._enter(A, E)
         _check(self._lib.mil_decon_init_single(self._h, _ptr(A), _ptr(E), int(const_init)), "mil_decon_init_single")
+        self._leave()
 
     def init_dual(self, A, B, E, const_init=False):
-        self._enter()
+        self._enter(A, B, E)
         _check(self._lib.mil_decon_init_dual(self._h, _ptr(A), _ptr(B), _ptr(E), int(const_init)),
                "mil_decon_init_dual")
+        self._leave()
 
     def run_single(self, E, A, otf, otf_bp, iters):
-        self._enter()
+        self._enter(E, A, otf, otf_bp)
         _check(self._lib.mil_decon_run_single(self._h, _ptr(E), _ptr(A), _ptr(otf), _ptr(otf_bp), int(iters)),
                "mil_decon_run_single")
+        self._leave()
 
     def run_dual(self, E, A, B, otf1, otf2, otf_bp1, otf_bp2, iters):
-        self._enter()
+        self._enter(E, A, B, otf1, otf2, otf_bp1, otf_bp2)
         _check(self._lib.mil_decon_run_dual(self._h, _ptr(E), _ptr(A), _ptr(B), _ptr(otf1), _ptr(otf2),
                                             _ptr(otf_bp1), _ptr(otf_bp2), int(iters)), "mil_decon_run_dual")
+        self._leave()
 
     def sync(self):
         _check(self._lib.mil_decon_sync(self._h), "mil_decon_sync")

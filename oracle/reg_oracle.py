@@ -19,8 +19,26 @@ from __future__ import annotations
 
 import numpy as np
 
+import ctypes as _C
+
 f32 = np.float32
 NDIM = 12
+
+# The reference's `cos(theta)` / `sin(theta)` on a float argument resolve to the float overloads, i.e. the C library's
+# cosf / sinf (src/api_subfunc.cu:661-662, 795-796, 805-806, 815-816).  NumPy's float32 cos / sin are its own SIMD
+# routines and differ from glibc's in the last bit for ~9 % of arguments, so the oracle calls libm -- checked bit-exact
+# against the compiled reference helpers in tests/test_oracle_pinned.py.
+_libm = _C.CDLL("libm.so.6")
+_libm.cosf.restype = _libm.sinf.restype = _C.c_float
+_libm.cosf.argtypes = _libm.sinf.argtypes = [_C.c_float]
+
+
+def _cosf(a):
+    return f32(_libm.cosf(float(f32(a))))
+
+
+def _sinf(a):
+    return f32(_libm.sinf(float(f32(a))))
 
 
 # ---------------------------------------------------------------- matrices
@@ -74,13 +92,13 @@ def dof9tomatrix(p_dof, dof_num):
     t2 = np.zeros(12, dtype=f32)
     t2[3], t2[7], t2[11] = x, y, z
     t2[0], t2[5], t2[10] = a, b, c
-    ca, sa = f32(np.cos(alpha)), f32(np.sin(alpha))
+    ca, sa = _cosf(alpha), _sinf(alpha)
     t3 = np.array([ca, sa, 0, 0, -sa, ca, 0, 0, 0, 0, 1, 0], dtype=f32)  # Rz  :795-797
     t1 = matrixmultiply(t2, t3)
-    cb, sb = f32(np.cos(beta)), f32(np.sin(beta))
+    cb, sb = _cosf(beta), _sinf(beta)
     t3 = np.array([1, 0, 0, 0, 0, cb, sb, 0, 0, -sb, cb, 0], dtype=f32)  # Rx  :805-807
     t2 = matrixmultiply(t1, t3)
-    ct, st = f32(np.cos(theta)), f32(np.sin(theta))
+    ct, st = _cosf(theta), _sinf(theta)
     t3 = np.array([ct, 0, -st, 0, 0, 1, 0, 0, st, 0, ct, 0], dtype=f32)  # Ry  :815-817
     return matrixmultiply(t2, t3)
 
@@ -93,7 +111,7 @@ def rot2matrix(theta, sx, sy, sz, rot_axis):
     t3 = np.zeros(12, dtype=f32)
     t1[0] = t1[5] = t1[10] = 1
     t3[0] = t3[5] = t3[10] = 1
-    c, s = f32(np.cos(theta)), f32(np.sin(theta))
+    c, s = _cosf(theta), _sinf(theta)
     if rot_axis == 1:
         t1[7], t1[11] = sy // 2, sz // 2
         t2[:] = [1, 0, 0, 0, 0, c, s, 0, 0, -s, c, 0]
@@ -128,15 +146,18 @@ def checkmatrix(m, sx, sy, sz):
 
 
 # ---------------------------------------------------------------- sampling
-def _coords(m, shape):
+def _coords(m, shape, z_range=None):
     """Texture coordinates of every target voxel, float32, evaluated exactly as
     ``d_aff[0]*ix + d_aff[1]*iy + d_aff[2]*iz + d_aff[3] + 0.5`` left to right without
-    FMA contraction (include/cukernel.cuh:510-512, 539-541)."""
+    FMA contraction (include/cukernel.cuh:510-512, 539-541).  ``z_range = (z0, z1)`` restricts the
+    result to that slab of target planes (full-size fixtures are computed slab by slab)."""
     sz, sy, sx = shape
+    z0, z1 = (0, sz) if z_range is None else z_range
+    shape = (z1 - z0, sy, sx)
     m = np.asarray(m, dtype=f32)
     ix = np.arange(sx, dtype=f32)[None, None, :]
     iy = np.arange(sy, dtype=f32)[None, :, None]
-    iz = np.arange(sz, dtype=f32)[:, None, None]
+    iz = np.arange(z0, z1, dtype=f32)[:, None, None]
     half = f32(0.5)
     out = []
     for r in range(3):
@@ -182,23 +203,25 @@ def _trilinear(src, tx, ty, tz):
     return (wz0 * c0 + wz1 * c1).astype(f32)
 
 
-def affine_transform(src, m, out_shape):
+def affine_transform(src, m, out_shape, z_range=None):
     """affinetransformkernel, include/cukernel.cuh:501-524: non-strict lower bound
     ``0 <= t < s2`` on the +0.5 coordinates, 0 outside."""
     src = np.asarray(src, dtype=f32)
-    tx, ty, tz = _coords(m, out_shape)
+    tx, ty, tz = _coords(m, out_shape, z_range)
     s2z, s2y, s2x = src.shape
     valid = ((tx >= 0) & (tx < f32(s2x)) & (ty >= 0) & (ty < f32(s2y)) & (tz >= 0) & (tz < f32(s2z)))
     v = _trilinear(src, tx, ty, tz)
     return np.where(valid, v, f32(0)).astype(f32)
 
 
-def corr_sums(target, src, m):
+def corr_sums(target, src, m, z_range=None):
     """corrkernel, include/cukernel.cuh:526-556: strict ``0 < t < s2``; returns
-    (sum s*s, sum s*t) accumulated in float64."""
+    (sum s*s, sum s*t) accumulated in float64.  With ``z_range`` only that slab of target planes."""
     target = np.asarray(target, dtype=f32)
     src = np.asarray(src, dtype=f32)
-    tx, ty, tz = _coords(m, target.shape)
+    tx, ty, tz = _coords(m, target.shape, z_range)
+    if z_range is not None:
+        target = target[z_range[0]:z_range[1]]
     s2z, s2y, s2x = src.shape
     valid = ((tx > 0) & (tx < f32(s2x)) & (ty > 0) & (ty < f32(s2y)) & (tz > 0) & (tz < f32(s2z)))
     s = np.where(valid, _trilinear(src, tx, ty, tz), f32(0)).astype(np.float64)

@@ -12,7 +12,16 @@ f32 = np.float32
 SHAPES = [(16, 16, 16), (32, 16, 64), (16, 64, 32), (64, 32, 128), (128, 128, 128), (32, 256, 512), (256, 64, 16),
           # the 64*k boxes of snapTransformSize: radices 3, 5, 7, 11, 13 on every axis
           (16, 192, 320), (192, 16, 384), (320, 64, 192), (64, 448, 448), (16, 704, 576), (576, 16, 704),
-          (16, 832, 640), (896, 16, 832), (16, 960, 896), (640, 16, 960), (16, 768, 768), (768, 32, 64)]
+          (16, 832, 640), (896, 16, 832), (16, 960, 896), (640, 16, 960), (16, 768, 768), (768, 32, 64),
+          # every remaining instantiation of csrc/fft.hip's dispatch tables, in y AND z position: col_kernel<512>
+          # (the benchmark's y pass), <384>, <1024>, y 320 / 576 / 640 / 896, z 448 / 704 / 832 / 960 ...
+          (16, 512, 32), (512, 16, 32), (16, 384, 32), (384, 16, 32), (16, 1024, 32), (1024, 16, 32),
+          (16, 320, 64), (16, 576, 32), (16, 640, 32), (16, 896, 32),
+          (448, 16, 32), (704, 16, 32), (832, 16, 32), (960, 16, 32),
+          # ... and x_kernel<128>, <512>, <1024> (nx = 256, 1024, 2048)
+          (16, 16, 256), (16, 16, 1024), (16, 16, 2048),
+          # BASELINE.json configs 2-4: the benchmark box itself against a float64 DFT
+          (256, 512, 512)]
 
 
 @pytest.fixture(scope="module")
@@ -80,6 +89,40 @@ def test_backends_agree_on_rl(dev):
     floor = float(np.mean(np.abs(want)))
     for o in outs:
         assert float(np.max(np.abs(o - want) / np.maximum(np.abs(want), floor))) < 1e-5
+
+
+def test_backends_agree_at_benchmark_size(dev):
+    """20 single-view and 20 dual-view RL iterations at 512 x 512 x 256 (BASELINE.json configs 2, 3): the hand-written
+    transforms (csrc/fft.hip) against the rocFFT backend on the same closed-form inputs, 1e-5 relative."""
+    import torch
+    from tests import fullsize_inputs as fi
+    shape = fi.FULL_SHAPE
+    A, B = T(fi.hash_volume(shape, 1)), T(fi.hash_volume(shape, 2))
+    pa, pb = T(fi.psf_a()), T(fi.psf_b())
+    outs = {}
+    for backend in (dev.DeconEngine.ROCFFT, dev.DeconEngine.FUSED):
+        eng = dev.DeconEngine(shape, backend=backend)
+        assert eng.backend == backend
+        oa, ba = eng.gen_otf(pa), eng.gen_otf(pa, flip=True)
+        ob, bb = eng.gen_otf(pb), eng.gen_otf(pb, flip=True)
+        a, b = A.clone(), B.clone()
+        E = torch.empty_like(a)
+        eng.init_single(a, E)
+        eng.run_single(E, a, oa, ba, 20)
+        eng.sync()
+        sv = E.clone()
+        a = A.clone()
+        eng.init_dual(a, b, E)
+        eng.run_dual(E, a, b, oa, ob, ba, bb, 20)
+        eng.sync()
+        outs[backend] = (sv, E.clone())
+        eng.close()
+        del oa, ba, ob, bb
+    for k in (0, 1):
+        want, got = outs[dev.DeconEngine.ROCFFT][k].double(), outs[dev.DeconEngine.FUSED][k].double()
+        floor = float(want.abs().mean())
+        err = float(((got - want).abs() / torch.clamp(want.abs(), min=floor)).max())
+        assert err < 1e-5, ("single" if k == 0 else "dual", err)
 
 
 def test_snap_sized_box_runs_rl_on_the_fused_backend(dev):

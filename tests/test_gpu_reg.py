@@ -261,9 +261,78 @@ def test_reg2d_matches_oracle(choice):
         assert abs(tmx[2] - 3.3) < 1.0 and abs(tmx[5] + 2.2) < 1.0
 
 
-# ---------------------------------------------------------------- benchmark size, properties only
+# ---------------------------------------------------------------- benchmark size against the oracle's fixture
+def test_full_size_cost_and_resample_vs_oracle_fixture(dev, api):
+    """BASELINE.json config 4 AT the benchmark size (512 x 512 x 256): correlation-cost sums for six matrices through
+    the general kernel and every padded-source kernel (include/cukernel.cuh:526-556), the resampled source for two
+    of them (include/cukernel.cuh:501-524) and the initial ZNCC of reg3d_affine1 (src/api_subfunc.cu:2879-2881),
+    against oracle outputs committed as a fixture (tests/golden/make_golden_fullsize.py)."""
+    import torch
+    from tests import fullsize_inputs as fi
+    g = np.load(os.path.join(GOLD, "fullsize_reg.npz"))
+    shape = fi.FULL_SHAPE
+    tgt_raw, src_raw = fi.hash_volume(shape, 1), fi.hash_volume(shape, 3)
+    tgt_ms, tgt_sum = ro.mean_subtract(tgt_raw)
+    src_ms, src_sum = ro.mean_subtract(src_raw)
+    assert tgt_sum == float(g["tgt_sum"]) and src_sum == float(g["src_sum"])  # the inputs are the fixture's inputs
+    t_dev, s_dev = T(tgt_ms), T(src_ms)
+    pad = dev.PaddedSource(s_dev)
+    for i, m in enumerate(g["mats"]):
+        wss, wst = g["corr_sums"][i]
+        ss, st = dev.corr_sums(t_dev, s_dev, m)
+        assert abs(ss - wss) <= 1e-12 * wss and abs(st - wst) <= 1e-12 * wss, (i, ss, st, wss, wst)
+        for kern in (-1, 0, 1, 2):
+            dev.corr_padded_force_kernel(kern)
+            assert dev.corr_sums(t_dev, pad, m) == (ss, st), f"matrix {i}, padded kernel {kern}"
+    dev.corr_padded_force_kernel(-1)
+    pad.close()
+    del t_dev, s_dev
+    src_dev = T(src_raw)
+    idx = torch.from_numpy(fi.sample_indices(int(np.prod(shape)))).cuda()
+    for i in (1, 3):
+        reg = dev.affine_resample(src_dev, g["mats"][i], shape)
+        got = reg.reshape(-1)[idx].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), g[f"resample{i}_samples"].view(np.uint32)), f"matrix {i}"
+        planes = reg.double().sum(dim=(1, 2)).cpu().numpy()
+        want = g[f"resample{i}_planes"]
+        assert np.all(np.abs(planes - want) <= 1e-12 * np.maximum(np.abs(want), 1.0)), f"matrix {i}"
+        assert int(torch.count_nonzero(reg)) == int(g[f"resample{i}_nonzero"])
+    # the same resample through the reference's entry point (regChoice 0 + input matrix, src/api_reg.cpp:264)
+    out, tmx, _ = api.reg3d(tgt_raw, src_raw, i_tmx=g["mats"][1], reg_choice=0, input_tmx=True)
+    assert np.array_equal(out.reshape(-1)[fi.sample_indices(out.size)].view(np.uint32),
+                          g["resample1_samples"].view(np.uint32))
+    # records[1] of the optimiser = ZNCC at the identity = (st / sqrt(ss)) / sd_t in float32
+    _, _, rec = dev.reg3d_affine(T(tgt_raw), src_dev, aff_method=1, it_limit=5)
+    ss0, st0 = g["corr_sums"][0]
+    want = f32(f32(st0 / np.sqrt(ss0)) / f32(np.sqrt(float(g["tgt_sumsq"]))))
+    assert abs(rec[1] - want) <= 2e-7 * abs(want), (rec[1], want)
+
+
+def test_registration_orders_itself_after_pending_stream_work(dev):
+    """Inputs still in flight on torch's current stream (a non_blocking copy from pinned memory, a kernel) when the call
+    is made: the entry points order their private stream after them -- no host synchronisation by the caller."""
+    import torch
+    rng = np.random.default_rng(3)
+    shape = (64, 96, 128)
+    host = torch.from_numpy(rng.uniform(10, 500, shape).astype(f32)).pin_memory()
+    want = None
+    for attempt in range(3):
+        big = torch.empty((256, 512, 512), device="cuda")
+        big.normal_()  # keeps stream 0 busy while the copy below is queued behind it
+        vol = torch.empty(shape, device="cuda")
+        vol.copy_(host, non_blocking=True)
+        moved = vol * 1.0
+        _, tmx, rec = dev.reg3d_affine(vol, moved, aff_method=1, it_limit=30)
+        if want is None:
+            torch.cuda.synchronize()
+            _, want_tmx, want = dev.reg3d_affine(vol, moved, aff_method=1, it_limit=30)
+        assert rec[1] > 0.999999 and rec[1] == want[1], (attempt, rec[1])
+        del big
+
+
+# ---------------------------------------------------------------- benchmark size, size-independent properties
 def test_full_size_registration_properties(dev):
-    """512x512x256 (BASELINE.json config 4): the oracle is too slow here, so size-independent properties.
+    """512x512x256 (BASELINE.json config 4), beside the fixture comparison above: size-independent properties.
     Identity resample is exact; ZNCC of a volume with itself is 1; the cost is linear in a target scale and blind to a
     target offset after mean removal; a known integer shift is what the cost prefers; Powell started at the optimum of
     a self-registration stays there."""
