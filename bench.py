@@ -11,10 +11,11 @@ collective on the data path; the only exchange is the gather of the XY maximum-i
 projections to rank 0 after the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      HBM roofline of the dominant kernel (the in-place y pass of the fused backend), timed
-                with HIP events on the engine's stream inside the timed region;
-  cpu_baseline  the oracle's NumPy restatement of the same RL iteration timed on this box's
-                host cores (N = 1 only), a bounded sample;
+  roofline      HBM roofline of the dominant kernel (z_conv of the fused backend: the top symbol of the rocprofv3
+                kernel stats), timed with HIP events on the engine's stream inside the timed region; the other
+                three kernel families are in extra.kernel_families;
+  cpu_baseline  the library's gpuMemMode 0 path (C++ restatement of the reference's CPU twin) timed on this
+                box's host cores (N = 1 only), a bounded sample: one thread like the reference + all cores;
   extra         dual-view it/s, reg3D voxels/s and the per-kernel-family time split.
 """
 import argparse
@@ -65,32 +66,26 @@ def gaussian_psf(shape, sigma_zyx):
     return (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
 
 
-def cpu_baseline(img_host, psf_host, iters, fft_workers=1):
-    """Oracle (NumPy restatement of decon_singleview_OTF1) on the host: `iters` RL iterations.
-
-    fft_workers > 1: the transforms run on scipy.fft's thread pool (same pocketfft code, multi-threaded), the
-    element-wise passes stay single-threaded -- the reference's CPU path threads nothing but the FFT either."""
-    from oracle import decon_oracle as do
-    if fft_workers > 1:
-        import scipy.fft as sfft
-        saved = (do.r2c, do.c2r)
-        do.r2c = lambda a: sfft.rfftn(a.astype(np.float32, copy=False), workers=fft_workers)
-        do.c2r = lambda s, F: sfft.irfftn(s, s=F, axes=(0, 1, 2), norm="forward", workers=fft_workers).astype(
-            np.float32, copy=False)
-        try:
-            return cpu_baseline(img_host, psf_host, iters, 1)
-        finally:
-            do.r2c, do.c2r = saved
-    F = img_host.shape
-    otf = do.gen_otf(psf_host, F)
-    otf_bp = do.gen_otf(do.flip3(psf_host), F)
-    A = do.clamp_small(img_host)
-    E = A.copy()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        E = do.rl_view_update(E, A, otf, otf_bp, F)
-    dt = time.perf_counter() - t0
-    return iters / dt, dt
+def cpu_baseline(img_host, psf_host, iters, threads):
+    """The library's own gpuMemMode 0 path -- the C++ restatement of the reference's CPU twin (decon_singleview_OTF0,
+    src/api_subfunc.cu:3310-3359: same order of operations, separate element-wise passes, bundled mixed-radix FFT in
+    place of FFTW) -- through the same libapi.h entry point the GPU path is called by.  `threads` = MIL_CPU_THREADS
+    (1 = the reference's behaviour).  Returns (iterations/s over the RL loop, loop seconds, whole-call seconds)."""
+    from microimagelib_amd import api
+    saved = os.environ.get("MIL_CPU_THREADS")
+    os.environ["MIL_CPU_THREADS"] = str(threads)
+    try:
+        t0 = time.perf_counter()
+        _, rec = api.decon_singleview(img_host, psf_host, iters, gpu_mem_mode=0)
+        whole = time.perf_counter() - t0
+    finally:
+        if saved is None:
+            os.environ.pop("MIL_CPU_THREADS", None)
+        else:
+            os.environ["MIL_CPU_THREADS"] = saved
+    assert rec[0] == 0, "gpuMemMode 0 did not run on the host"
+    loop_s = float(rec[8])
+    return iters / loop_s, loop_s, whole
 
 
 def main():
@@ -106,9 +101,9 @@ def main():
     ap.add_argument("--clock-warm-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=4)
-    ap.add_argument("--cpu-fft-threads", type=int, default=16,
-                    help="second CPU figure with the FFTs threaded (a 1-GPU box's share of host cores); 1 = skip")
+    ap.add_argument("--cpu-iters", type=int, default=4, help="RL iterations of the single-thread CPU baseline (~3 s each)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="second CPU figure on this many threads (a 1-GPU box's share of host cores); 1 = skip")
     # functional test of the N > 1 path on a one-GPU box: all ranks on cuda:0, collectives over gloo (never a measurement)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
@@ -167,14 +162,15 @@ def main():
     ALL_TIMERS = (mdev.DeconEngine.TIMER_UPDATE, mdev.DeconEngine.TIMER_RATIO, mdev.DeconEngine.TIMER_CMUL,
                   mdev.DeconEngine.TIMER_FFT)
     # Inside the timed region only the roofline kernel is bracketed with HIP events on the engine's stream
-    # (fused backend: the y pass, 4 launches per step and the largest share of it; rocFFT backend: the OTF
-    # product), and only every 4th launch of it (one per step).  An event pair is a pair of stream markers: the
+    # (fused backend: z_conv = z transform, OTF product, inverse z transform in one kernel -- the largest single
+    # symbol in the rocprofv3 kernel stats; rocFFT backend: the OTF product), and only every 2nd launch of it
+    # (one per step).  An event pair is a pair of stream markers: the
     # rocprofv3 trace shows 0 us between back-to-back kernels and 6-10 us across a marker, so bracketing all 8
     # launches of a step would cost several percent of it.  The other families are timed in a second,
     # un-clocked pass of the same K steps.
-    dom_timer = mdev.DeconEngine.TIMER_FFT if fused else mdev.DeconEngine.TIMER_CMUL
+    dom_timer = mdev.DeconEngine.TIMER_CMUL  # fused: z_conv, the largest single kernel symbol of the step
     if not os.environ.get("MIL_BENCH_NO_EVENTS"):  # diagnostic: how much the in-region markers cost
-        eng.timer_enable(dom_timer, 4 if fused else 2)
+        eng.timer_enable(dom_timer, 2)
 
     def fence():
         torch.cuda.synchronize()
@@ -243,7 +239,7 @@ def main():
         upd_key = [k for k in fam if k.startswith(("x_update", "rl_update"))][0]
         upd_frac = (round(fam[upd_key][2] / (upd_ms / upd_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     if upd_n and upd_ms > 0 else None)
-        dom = [k for k in fam if k.startswith("y_pass" if fused else "cmul_otf")][0]
+        dom = [k for k in fam if k.startswith("z_conv" if fused else "cmul_otf")][0]
         dom_bytes = fam[dom][2]
         dom_avg_ms = dom_ms / max(dom_n, 1)  # measured inside the timed region
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_n else None
@@ -261,6 +257,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "clock_warm_steps": args.clock_warm_steps,
+            "untimed_steps_total": args.warmup + args.clock_warm_steps,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -378,22 +376,27 @@ def main():
         img_host = img_a.cpu().numpy()
         del E, A
         torch.cuda.empty_cache()
-        its, secs = cpu_baseline(img_host, psf_a_host, args.cpu_iters)
+        its, secs, whole = cpu_baseline(img_host, psf_a_host, args.cpu_iters, 1)
         result["cpu_baseline"] = {
             "value": round(its, 4),
             "unit": "iterations/s",
             "cores": 1,
             "kind": "port",
-            "sample": f"{args.cpu_iters} RL iterations of the same 512x512x256 volume and PSF "
-                      f"(oracle/decon_oracle.py: NumPy pocketfft float32 + single-threaded element-wise), {secs:.1f} s",
+            "implementation": "libapi.so decon_singleview(gpuMemMode 0): C++ restatement of the reference's CPU twin "
+                              "(decon_singleview_OTF0 order of operations, separate single-op element-wise passes), "
+                              "bundled mixed-radix FFT (FFTW is not on this box)",
+            "sample": f"{args.cpu_iters} RL iterations of the same 512x512x256 volume and PSF on 1 thread like the "
+                      f"reference: {secs:.1f} s in the loop, {whole:.1f} s for the whole call (OTFs included)",
             "host_cores_available": os.cpu_count(),
         }
-        if args.cpu_fft_threads > 1:
-            its_mt, secs_mt = cpu_baseline(img_host, psf_a_host, args.cpu_iters, args.cpu_fft_threads)
-            result["cpu_baseline"]["fft_threaded"] = {
-                "value": round(its_mt, 4), "unit": "iterations/s", "cores": args.cpu_fft_threads,
-                "sample": f"same {args.cpu_iters} iterations with the transforms on {args.cpu_fft_threads} threads "
-                          f"(scipy.fft workers; element-wise passes single-threaded as in the reference), {secs_mt:.1f} s"}
+        n_thr = min(args.cpu_threads, os.cpu_count() or 1)
+        if n_thr > 1:
+            it_mt = 3 * args.cpu_iters
+            its_mt, secs_mt, whole_mt = cpu_baseline(img_host, psf_a_host, it_mt, n_thr)
+            result["cpu_baseline"]["all_cores"] = {
+                "value": round(its_mt, 4), "unit": "iterations/s", "cores": n_thr,
+                "sample": f"{it_mt} iterations of the same call with MIL_CPU_THREADS={n_thr} (every pass threaded): "
+                          f"{secs_mt:.1f} s in the loop, {whole_mt:.1f} s whole"}
     elif rank == 0:
         result["cpu_baseline"] = None
 

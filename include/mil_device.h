@@ -141,6 +141,13 @@ void mil_dof9tomatrix(float *m12, const float *p9, int dofNum);     /* dof9tomat
 void mil_matrixmultiply(float *m, const float *m1, const float *m2);/* matrixmultiply :584 */
 void mil_rot2matrix(float *m12, float theta, long long sx, long long sy, long long sz, int rotAxis); /* :626 */
 
+
+/* Host 3-D real transforms of the gpuMemMode 0 path (reference: fftwf_plan_dft_r2c_3d / c2r_3d at
+ * src/api_subfunc.cu:3334-3336; bundled mixed-radix implementation, csrc/cpu_fft.cpp).  HOST pointers; nx even.
+ * inverse == 0: h_real [nz][ny][nx] -> h_spec [nz][ny][nx/2+1] complex64; inverse != 0: h_spec -> h_real, unnormalised,
+ * h_spec destroyed.  threads <= 0: MIL_CPU_THREADS or 1. */
+int mil_cpu_rfft3d(float *h_real, void *h_spec, int nx, int ny, int nz, int inverse, int threads);
+
 #ifdef __cplusplus
 }
 #endif

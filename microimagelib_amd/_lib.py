@@ -103,6 +103,7 @@ SIGNATURES = {
     "mil_matrix2p": (None, [c_float_p, c_float_p]),
     "mil_dof9tomatrix": (None, [c_float_p, c_float_p, C.c_int]),
     "mil_matrixmultiply": (None, [c_float_p, c_float_p, c_float_p]),
+    "mil_cpu_rfft3d": (C.c_int, [c_float_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mil_rot2matrix": (None, [c_float_p, C.c_float, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]),
 }
 

@@ -19,7 +19,7 @@ int main(int argc, char **argv) {
     p.add("-o", "<filename>", "Output filename of the deconvolved image (mandatory)", [&](const char *v) { out_path = v; });
     p.add("-bp", "<filename>", "Backward projector filename [flip of PSF]", [&](const char *v) { bp_path = v; unmatch = true; });
     p.add("-it", "<int>", "Iteration number of the deconvolution [20]", [&](const char *v) { iters = atoi(v); });
-    p.add("-gm", "<int>", "-1 automatic | 0 CPU (not provided by this build) | 1 efficient GPU | 2 memory-saved GPU [-1]",
+    p.add("-gm", "<int>", "-1 automatic | 0 CPU (host RL, MIL_CPU_THREADS=n) | 1 efficient GPU | 2 memory-saved GPU [-1]",
           [&](const char *v) { mem_mode = atoi(v); });
     p.add("-dev", "<int>", "GPU device [0]", [&](const char *v) { device = atoi(v); });
     p.add("-cON", nullptr, "constant as initialization", [&](const char *) { const_init = true; });

@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
     p.add("-it", "<int>", "Iteration number of the deconvolution [10]", [&](const char *v) { iters = atoi(v); });
     p.add("-cON", nullptr, "constant as initialization", [&](const char *) { const_init = true; });
     p.add("-cOFF", nullptr, "average of the two views as initialization [default]", [&](const char *) { const_init = false; });
-    p.add("-gm", "<int>", "-1 automatic | 0 CPU (not provided) | 1 efficient GPU | 2 memory-saved GPU [-1]",
+    p.add("-gm", "<int>", "-1 automatic | 0 CPU (host RL, MIL_CPU_THREADS=n) | 1 efficient GPU | 2 memory-saved GPU [-1]",
           [&](const char *v) { mem_mode = atoi(v); });
     p.add("-dev", "<int>", "GPU device [0]", [&](const char *v) { device = atoi(v); });
     p.add("-bit", "<int>", "Output image bit: 16 or 32 [same as input image]",

@@ -7,6 +7,8 @@
 #include <memory>
 
 #include "../../include/libapi.h"
+#include "cpu_decon.h"
+#include "cpu_fft.h"
 #include "decon.h"
 
 using namespace mil;
@@ -46,22 +48,50 @@ Geometry make_geometry(const unsigned int *imSize, const unsigned int *psfSize) 
     return g;
 }
 
-// Resolve the requested memory mode.  288 GB of HBM: the reference's memory-saving mode 2 is run
-// as mode 1; the CPU mode 0 is not part of this build.  Returns the mode used, or -1.
+// Resolve the requested memory mode.  288 GB of HBM: the reference's memory-saving mode 2 is run as mode 1.  In auto
+// mode (-1) the reference's ladder is 1 -> 2 -> 0 by free device memory (src/api_decon.cpp:116-134, :398-416); here
+// it is 1 -> 0: a volume that does not fit the device is deconvolved on the host.  A missing or failing device is
+// NOT a reason to fall back -- that stays an error (hipMemGetInfo throws).  Returns the mode used.
 int resolve_mode(int requested, size_t bytes_needed, bool verbose) {
     if (requested == 1 || requested == 2) return 1;
-    if (requested == -1) {
-        size_t free_b = 0, total_b = 0;
-        MIL_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (free_b > bytes_needed) {
-            if (verbose) printf("\t... GPU memory is sufficient, processing in efficient mode !!!\n");
-            return 1;
-        }
-        fprintf(stderr, "[microimagelib_amd] decon: %.0f MB needed, %.0f MB free on the device\n",
-                bytes_needed / 1048576.0, free_b / 1048576.0);
-        return -1;
+    size_t free_b = 0, total_b = 0;
+    MIL_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (const char *cap = getenv("MIL_DECON_FREE_MB_CAP")) {  // test aid: pretend the device has less free memory
+        const size_t cap_b = (size_t)atoll(cap) << 20;
+        if (cap_b < free_b) free_b = cap_b;
     }
-    return -1;
+    if (free_b > bytes_needed) {
+        if (verbose) printf("\t... GPU memory is sufficient, processing in efficient mode !!!\n");
+        return 1;
+    }
+    fprintf(stderr, "[microimagelib_amd] decon: %.0f MB needed, %.0f MB free on the device: CPU mode (gpuMemMode 0)\n",
+            bytes_needed / 1048576.0, free_b / 1048576.0);
+    return 0;
+}
+
+// gpuMemMode 0 (reference src/api_decon.cpp:151-197, :430-520): no device call at all.
+int run_cpu(float *h_decon, const float *h_img1, const float *h_img2, const float *h_psf1, const float *h_psf2,
+            const float *h_psf_bp1, const float *h_psf_bp2, const Geometry &g, bool dual, bool constInit, int iters,
+            bool verbose, bool unmatch, float *deconRecords, double t_start) {
+    cpu::DeconCpuArgs a;
+    a.out = h_decon;
+    a.img[0] = h_img1; a.img[1] = h_img2;
+    a.psf[0] = h_psf1; a.psf[1] = h_psf2;
+    a.psf_bp[0] = h_psf_bp1; a.psf_bp[1] = h_psf_bp2;
+    a.im = g.im; a.psf_dims = g.psf; a.box = g.box;
+    a.dual = dual; a.const_init = constInit; a.unmatch = unmatch; a.verbose = verbose;
+    a.iterations = iters;
+    double sec[3] = {0, 0, 0};
+    a.seconds = sec;
+    if (verbose) printf("...CPU deconvolution (gpuMemMode 0), %d thread(s)\n", cpu::default_threads());
+    const int rc = cpu::decon(a);
+    deconRecords[0] = 0.f;
+    for (int i = 1; i <= 5; ++i) deconRecords[i] = 0.f;  // no device memory snapshots in CPU mode
+    deconRecords[6] = (float)(now_s() - t_start - sec[2]);
+    deconRecords[7] = (float)sec[0];
+    deconRecords[8] = (float)sec[1];
+    deconRecords[9] = (float)(now_s() - t_start);
+    return rc;
 }
 
 void upload_volume(float *d_dst, float *d_stage, const float *h_src, const Geometry &g, hipStream_t s) {
@@ -103,18 +133,17 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
                                 unsigned int *psfSize, bool flagConstInitial, int itNumForDecon, int deviceNum,
                                 int gpuMemMode, bool verbose, float *deconRecords, bool flagUnmatch,
                                 float *h_psf_bp) {
-    if (gpuMemMode == 0) {
-        printf("\n****CPU deconvolution (gpuMemMode 0) is not provided by the MI355X build ****\n");
-        return 1;
-    }
     if (gpuMemMode < -1 || gpuMemMode > 2) {
         printf("\n****Wrong gpuMemMode setup, no deconvolution performed !!! ****\n");
         return 1;  // reference src/api_decon.cpp:316-318
     }
     return guarded("decon_singleview", [&]() -> int {
         const double t_start = now_s();
-        MIL_HIP(hipSetDevice(deviceNum));
         const Geometry g = make_geometry(imSize, psfSize);
+        if (gpuMemMode == 0)
+            return run_cpu(h_decon, h_img, nullptr, h_psf, nullptr, h_psf_bp, nullptr, g, false, flagConstInitial,
+                           itNumForDecon, verbose, flagUnmatch, deconRecords, t_start);
+        MIL_HIP(hipSetDevice(deviceNum));
         if (verbose) {
             printf("Image information:\n");
             printf("...Image size %lld x %lld x %lld\n", g.im.nx, g.im.ny, g.im.nz);
@@ -126,7 +155,9 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         const size_t need = (3 * g.n_box + g.n_psf + (g.padded ? g.n_im : 0)) * sizeof(float) +
                             4 * g.n_spec * sizeof(float2);
         const int mode = resolve_mode(gpuMemMode, need, verbose);
-        if (mode < 0) return 1;
+        if (mode == 0)
+            return run_cpu(h_decon, h_img, nullptr, h_psf, nullptr, h_psf_bp, nullptr, g, false, flagConstInitial,
+                           itNumForDecon, verbose, flagUnmatch, deconRecords, t_start);
         deconRecords[0] = (float)mode;
         const double t_init = now_s();
 
@@ -162,18 +193,17 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
                               float *h_psf2, unsigned int *psfSize, bool flagConstInitial, int itNumForDecon,
                               int deviceNum, int gpuMemMode, bool verbose, float *deconRecords, bool flagUnmatch,
                               float *h_psf_bp1, float *h_psf_bp2) {
-    if (gpuMemMode == 0) {
-        printf("\n****CPU deconvolution (gpuMemMode 0) is not provided by the MI355X build ****\n");
-        return -1;
-    }
     if (gpuMemMode < -1 || gpuMemMode > 2) {
         printf("\n****Wrong gpuMemMode setup, no deconvolution performed !!! ****\n");
         return -1;  // reference src/api_decon.cpp:685-687
     }
     return guarded("decon_dualview", [&]() -> int {
         const double t_start = now_s();
-        MIL_HIP(hipSetDevice(deviceNum));
         const Geometry g = make_geometry(imSize, psfSize);
+        if (gpuMemMode == 0)
+            return run_cpu(h_decon, h_img1, h_img2, h_psf1, h_psf2, h_psf_bp1, h_psf_bp2, g, true, flagConstInitial,
+                           itNumForDecon, verbose, flagUnmatch, deconRecords, t_start);
+        MIL_HIP(hipSetDevice(deviceNum));
         if (verbose) {
             printf("\tImage information:\n");
             printf("\t... Image size %lld x %lld x %lld\n", g.im.nx, g.im.ny, g.im.nz);
@@ -184,7 +214,9 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         const size_t need = (4 * g.n_box + g.n_psf + (g.padded ? g.n_im : 0)) * sizeof(float) +
                             6 * g.n_spec * sizeof(float2);
         const int mode = resolve_mode(gpuMemMode, need, verbose);
-        if (mode < 0) return -1;
+        if (mode == 0)
+            return run_cpu(h_decon, h_img1, h_img2, h_psf1, h_psf2, h_psf_bp1, h_psf_bp2, g, true, flagConstInitial,
+                           itNumForDecon, verbose, flagUnmatch, deconRecords, t_start);
         deconRecords[0] = (float)mode;
         const double t_init = now_s();
 

@@ -5,6 +5,7 @@
 #include <map>
 #include <memory>
 
+#include "cpu_fft.h"
 #include "decon.h"
 #include "powell.h"
 #include "reg.h"
@@ -343,6 +344,16 @@ void mil_dof9tomatrix(float *m12, const float *p9, int dofNum) { dof9tomatrix(m1
 void mil_matrixmultiply(float *m, const float *m1, const float *m2) { matrixmultiply(m, m1, m2); }
 void mil_rot2matrix(float *m12, float theta, long long sx, long long sy, long long sz, int rotAxis) {
     rot2matrix(m12, theta, sx, sy, sz, rotAxis);
+}
+
+int mil_cpu_rfft3d(float *h_real, void *h_spec, int nx, int ny, int nz, int inverse, int threads) {
+    return guarded("mil_cpu_rfft3d", [&] {
+        if (!h_real || !h_spec) throw Error(-1, "mil_cpu_rfft3d: null argument");
+        cpu::Rfft3D plan(dims3(nx, ny, nz), threads > 0 ? threads : cpu::default_threads());
+        if (inverse) plan.inverse((float2 *)h_spec, h_real);
+        else plan.forward(h_real, (float2 *)h_spec);
+        return 0;
+    });
 }
 
 }  // extern "C"

@@ -96,21 +96,29 @@ def test_golden_otf(dev, tag):
 
 
 # ---------------------------------------------------------------- error behaviour of the C API
-def test_cpu_mode_is_refused(api):
+def test_bad_memory_mode_is_refused(api):
     img = np.ones((16, 16, 16), dtype=f32)
     psf = np.ones((3, 3, 3), dtype=f32)
-    with pytest.raises(api.LibApiError) as e:
-        api.decon_singleview(img, psf, 1, gpu_mem_mode=0)
-    assert e.value.code == 1
-    with pytest.raises(api.LibApiError) as e:
-        api.decon_dualview(img, img, psf, psf, 1, gpu_mem_mode=0)
-    assert e.value.code == -1
     with pytest.raises(api.LibApiError) as e:
         api.decon_singleview(img, psf, 1, gpu_mem_mode=7)  # reference src/api_decon.cpp:316-318
     assert e.value.code == 1
     with pytest.raises(api.LibApiError) as e:
         api.decon_dualview(img, img, psf, psf, 1, gpu_mem_mode=7)  # :685-687
     assert e.value.code == -1
+
+
+def test_auto_mode_ladder(api, monkeypatch):
+    """gpuMemMode -1 (reference src/api_decon.cpp:116-134): enough free HBM -> mode 1 on the GPU; not enough -> the
+    host path, mode 0 (the reference's memory-saving rung 2 does not exist on 288 GB).  Both give the oracle's result;
+    deconRecords[0] says which one ran.  The explicit mode 0 is covered without a GPU in tests/test_cpu_mode.py."""
+    g = np.load(os.path.join(GOLD, "decon_sv_small.npz"))
+    out, rec = api.decon_singleview(g["img"], g["psf"], int(g["iters"]), gpu_mem_mode=-1)
+    assert rec[0] == 1 and rel_err(out, g["expected"]) < RTOL
+    monkeypatch.setenv("MIL_DECON_FREE_MB_CAP", "1")  # test aid: pretend 1 MB is free
+    out, rec = api.decon_singleview(g["img"], g["psf"], int(g["iters"]), gpu_mem_mode=-1)
+    assert rec[0] == 0 and rel_err(out, g["expected"]) < RTOL
+    out, rec = api.decon_singleview(g["img"], g["psf"], int(g["iters"]), gpu_mem_mode=1)  # explicit mode: no ladder
+    assert rec[0] == 1 and rel_err(out, g["expected"]) < RTOL
 
 
 def test_memory_mode_2_runs_as_mode_1(api):
@@ -202,10 +210,11 @@ def _check_fullsize(got, g, tag):
     floor = float(g[f"{tag}_mean_abs"])
     err = float(np.max(np.abs(samples.astype(np.float64) - want) / np.maximum(np.abs(want), floor)))
     assert err < RTOL, (tag, err)
-    # every voxel takes part in a plane sum: rounding differences between two float32 transforms average out over the
-    # 262 144 voxels of a plane, a wrong voxel does not
+    # every voxel takes part in a plane sum.  Measured (tools/fullsize_diag.py, profiles/r02/fullsize_parity.txt): after
+    # 20 iterations the fused backend, the rocFFT backend and the oracle lie 0.6-0.7e-6 (single view) / 1.4-1.7e-6 (dual
+    # view) from one another per plane -- the drift of float32 RL itself; 4e-6 leaves room for that and nothing else
     perr = float(np.max(np.abs(planes - g[f"{tag}_planes"]) / np.abs(g[f"{tag}_planes"])))
-    assert perr < 1e-6, (tag, perr)
+    assert perr < 4e-6, (tag, perr)
     return err, perr
 
 
