@@ -105,7 +105,8 @@ void mil_padded_source_destroy(mil_padded_source *p);
 int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, int tx, int ty, int tz,
                          const float *m12, double *h_out, void *stream);
 /* test / profiling aid (process-wide): pin the padded-source kernel -- 0 plain layout + plane reuse, 1 row-pair layout,
- * 2 row-pair layout + plane reuse; -1 (default) chooses per matrix.  Every choice returns the same sums. */
+ * 2 row-pair layout + plane reuse, 3 / 4 / 5 the same with two voxels per lane (target widths that are multiples of 128;
+ * otherwise the one-voxel form runs); -1 (default) chooses per matrix.  Every choice returns the same sums. */
 int mil_corr_padded_force_kernel(int kernel);
 /* host logic only (no GPU needed): which of the three the per-matrix choice takes for m12 */
 int mil_corr_padded_pick_kernel(const float *m12);

@@ -81,9 +81,22 @@ __device__ __forceinline__ void corr_block_sum(const double *p, const double *q,
 // slots and publishes.  (~3 * 10^4 workgroups on ONE counter serialise in the memory-side atomic unit, and one
 // workgroup summing 6 * 10^4 doubles alone is a long latency-bound tail.)  Which workgroup is "last" varies from run to
 // run; what it adds, and in which order, does not.
+//
+// corr_publish_as: the same with an explicit partial index b -- a workgroup that covers the voxels of several
+// "virtual" workgroups of the 64 x 4 x 16 decomposition (corr_pair_kernel: two of them) publishes once per virtual
+// workgroup, so that the partials, their grouping and the order of every addition are those of the one-voxel-per-lane
+// kernels: all cost kernels return the same bits.
+template <int THREADS>
+__device__ __forceinline__ void corr_publish_as(int b, double a0, double a1, CorrTail t, double *lds, int *flag);
+
 template <int THREADS>
 __device__ __forceinline__ void corr_publish(double a0, double a1, CorrTail t, double *lds, int *flag) {
-    const int b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    corr_publish_as<THREADS>(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), a0, a1, t, lds, flag);
+}
+
+template <int THREADS>
+__device__ __forceinline__ void corr_publish_as(int b, double a0, double a1, CorrTail t, double *lds, int *flag) {
+    __syncthreads();  // *flag and lds may still be read by a previous publish of this workgroup
     const int groups = t.nblocks < kCorrCounters ? t.nblocks : kCorrCounters;
     const int grp = b % groups;
     const int members = (t.nblocks - grp + groups - 1) / groups;

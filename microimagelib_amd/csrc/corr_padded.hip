@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mil {
 namespace k {
@@ -41,7 +42,22 @@ struct PaddedArgs {
     int plane4;           // padded plane pitch in bytes
     int origin4;          // byte offset of source voxel (0, 0, 0) inside the padded volume
     unsigned bytes;       // size of the padded volume
+    int gx, gy;           // tiles along x and y of the launched kernel (grid = gx * gy * gz workgroups, one-dimensional)
 };
+
+// Workgroup -> tile: one-dimensional grid, x fastest.  An XCD-aware order (each of the 8 XCDs, with its private L2, takes a
+// contiguous eighth of the tiles instead of every 8th tile) was built and measured: it removes the duplicate fetches of the
+// 128-byte lines on the rim of each XCD's column stripe -- FETCH_SIZE 1.26 x -> 1.04 x the algorithmic 2R
+// (profiles/r02/reg_cost_experiment_corr_k0.json vs reg_cost_kernel.json) -- and changes nothing at the identity
+// (0.155 vs 0.156 ms) while rotations lose 3-5 % (10 deg: 0.245 vs 0.233 ms): these kernels are bound by the
+// address path and VALU issue, not by HBM, so the order stays plain.
+__device__ __forceinline__ void corr_tile_of_block(int gx, int gy, int &bx, int &by, int &bz) {
+    const unsigned tile = blockIdx.x;
+    bx = (int)(tile % (unsigned)gx);
+    const unsigned rest = tile / (unsigned)gx;
+    by = (int)(rest % (unsigned)gy);
+    bz = (int)(rest / (unsigned)gy);
+}
 
 // (lo, hi) = two adjacent source voxels; address = base + voffset (per lane) + soffset (uniform)
 __device__ __forceinline__ f32x2 gather_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
@@ -55,9 +71,11 @@ __global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__re
     __shared__ double lds[2 * kTileY];
     __shared__ int last;
     const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
-    const int x = blockIdx.x * kTileX + lane;
-    const int y = blockIdx.y * kTileY + wave;
-    const int z0 = blockIdx.z * kStepsZ;
+    int bx, by, bz;
+    corr_tile_of_block(a.gx, a.gy, bx, by, bz);
+    const int x = bx * kTileX + lane;
+    const int y = by * kTileY + wave;
+    const int z0 = bz * kStepsZ;
     double ss = 0.0, st = 0.0;
     if (x < a.tx && y < a.ty) {
         const float ix = (float)x, iy = (float)y;
@@ -164,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__re
             a1 += lds[kTileY + w];
         }
     }
-    corr_publish<kThreads>(a0, a1, tail, lds, &last);
+    corr_publish_as<kThreads>(bx + a.gx * (by + a.gy * bz), a0, a1, tail, lds, &last);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -186,9 +204,11 @@ __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__r
     __shared__ double lds[2 * kTileY];
     __shared__ int last;
     const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
-    const int x = blockIdx.x * kTileX + lane;
-    const int y = blockIdx.y * kTileY + wave;
-    const int z0 = blockIdx.z * kStepsZ;
+    int bx, by, bz;
+    corr_tile_of_block(a.gx, a.gy, bx, by, bz);
+    const int x = bx * kTileX + lane;
+    const int y = by * kTileY + wave;
+    const int z0 = bz * kStepsZ;
     double ss = 0.0, st = 0.0;
     if (x < a.tx && y < a.ty) {
         const float ix = (float)x, iy = (float)y;
@@ -281,7 +301,270 @@ __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__r
             a1 += lds[kTileY + w];
         }
     }
-    corr_publish<kThreads>(a0, a1, tail, lds, &last);
+    corr_publish_as<kThreads>(bx + a.gx * (by + a.gy * bz), a0, a1, tail, lds, &last);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two voxels per lane, 64 apart in x.  The cost kernels above spend ~62 VALU instructions per voxel, 71 % of their run time
+// in VALU issue (rocprofv3 PMC, profiles/r01_final/reg_cost_kernel.json), and one address-path pass per voxel on a
+// 4-byte target load.  Here a lane owns target voxels (x, x + 64) -- the same lane of two neighbouring 64-wide workgroups,
+// so every gather of a wave still covers 64 consecutive source columns:
+//   * the coordinate chains of the two voxels run as ONE chain of 2-wide operations (v_pk_add_f32): each voxel's value
+//     goes through the reference's own sequence of float32 operations, so the bits do not change;
+//   * the validity window costs six compares per voxel -- but t is a non-decreasing (or non-increasing) function of x and
+//     of z under float32 evaluation (every operation of ((m0*x + m1*y) + m2*z) + m3 + 0.5 is monotone), so a lane
+//     whose two voxels lie in the window at the first AND the last z of its column segment lies in it throughout.  A wave
+//     in which that holds for every lane (all waves but those at the rim of the overlap) runs a loop without
+//     compares, selects or offset substitution.
+// Each voxel keeps its own float64 accumulators, and the sums are combined in the order the one-voxel-per-lane kernels
+// use -- a wave here covers two of their waves, a workgroup two of their workgroups, published separately
+// (corr_publish_as) -- so every cost kernel returns the same bits.
+template <bool PAIRS, bool REUSE>
+__global__ __launch_bounds__(kThreads) void corr_pair_kernel(const float *__restrict__ tgt,
+                                                           const float *__restrict__ srcp, PaddedArgs a,
+                                                           CorrTail tail, int old_grid_x) {
+    __shared__ double lds[4 * kTileY];
+    __shared__ int last;
+    const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
+    int bx, by, bz;
+    corr_tile_of_block(a.gx, a.gy, bx, by, bz);
+    const int x = bx * 2 * kTileX + lane;  // voxel A; voxel B sits kTileX further on (the next 64-wide workgroup of the
+                                           // one-voxel-per-lane decomposition); tx % 128 == 0 (host check)
+    const int y = by * kTileY + wave;
+    const int z0 = bz * kStepsZ;
+    const int z1 = (z0 + kStepsZ < a.tz) ? z0 + kStepsZ : a.tz;
+    double ssA = 0.0, stA = 0.0, ssB = 0.0, stB = 0.0;
+    const bool active = x < a.tx && y < a.ty;
+    const float iy = (float)y;
+    const f32x2 ixs = {(float)x, (float)(x + kTileX)};
+    const f32x2 half2 = {0.5f, 0.5f};
+    // per-axis constant part m0*x + m1*y of both voxels, (voxel A, voxel B)
+    const f32x2 HX = ixs * a.m[0] + (f32x2){a.m[1] * iy, a.m[1] * iy};
+    const f32x2 HY = ixs * a.m[4] + (f32x2){a.m[5] * iy, a.m[5] * iy};
+    const f32x2 HZ = ixs * a.m[8] + (f32x2){a.m[9] * iy, a.m[9] * iy};
+    auto coords = [&](int z, f32x2 &TX, f32x2 &TY, f32x2 &TZ) {
+        const float iz = (float)z;
+        const float zx = a.m[2] * iz, zy = a.m[6] * iz, zz = a.m[10] * iz;
+        TX = ((HX + (f32x2){zx, zx}) + (f32x2){a.m[3], a.m[3]}) + half2;
+        TY = ((HY + (f32x2){zy, zy}) + (f32x2){a.m[7], a.m[7]}) + half2;
+        TZ = ((HZ + (f32x2){zz, zz}) + (f32x2){a.m[11], a.m[11]}) + half2;
+    };
+    auto inside = [&](float tx_, float ty_, float tz_) {
+        return tx_ > 0 && tx_ < a.sxf && ty_ > 0 && ty_ < a.syf && tz_ > 0 && tz_ < a.szf;
+    };
+    bool whole = true;  // both voxels in the window at both ends of the z segment
+    if (active) {
+        f32x2 TX, TY, TZ;
+        coords(z0, TX, TY, TZ);
+        whole = inside(TX.x, TY.x, TZ.x) && inside(TX.y, TY.y, TZ.y);
+        coords(z1 - 1, TX, TY, TZ);
+        whole = whole && inside(TX.x, TY.x, TZ.x) && inside(TX.y, TY.y, TZ.y);
+    }
+    const bool fast = __all(whole) != 0;  // wave-uniform
+
+    struct Vox {
+        f32x2 wx, wy, wz;  // (1 - w, w)
+        unsigned off;
+        bool in;
+        float tv;
+    };
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(srcp), 0, (int)a.bytes, 0x00020000);
+    const unsigned sRow = (unsigned)a.row4, sPlane = (unsigned)a.plane4, sBoth = (unsigned)(a.plane4 + a.row4);
+    const char *tbase = reinterpret_cast<const char *>(tgt);
+    const unsigned tstep = 4u * (unsigned)a.tx * (unsigned)a.ty;
+
+    auto run = [&](auto check_tag) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+        unsigned toff = 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)y + (unsigned)a.ty * (unsigned)z0));
+        auto prepare = [&](int z, unsigned toff, Vox &A, Vox &B) {
+            f32x2 TX, TY, TZ;
+            coords(z, TX, TY, TZ);
+            if (CHECK) {
+                A.in = inside(TX.x, TY.x, TZ.x);
+                B.in = inside(TX.y, TY.y, TZ.y);
+            } else {
+                A.in = B.in = true;
+            }
+            const f32x2 BX = TX - half2, BY = TY - half2, BZ = TZ - half2;
+            const float fxA = floorf(BX.x), fyA = floorf(BY.x), fzA = floorf(BZ.x);
+            const float fxB = floorf(BX.y), fyB = floorf(BY.y), fzB = floorf(BZ.y);
+            A.wx.y = BX.x - fxA; A.wx.x = 1.0f - A.wx.y;
+            A.wy.y = BY.x - fyA; A.wy.x = 1.0f - A.wy.y;
+            A.wz.y = BZ.x - fzA; A.wz.x = 1.0f - A.wz.y;
+            B.wx.y = BX.y - fxB; B.wx.x = 1.0f - B.wx.y;
+            B.wy.y = BY.y - fyB; B.wy.x = 1.0f - B.wy.y;
+            B.wz.y = BZ.y - fzB; B.wz.x = 1.0f - B.wz.y;
+            constexpr int SH = PAIRS ? 3 : 2;
+            // nested multiply-adds (v_mad_i32_i24): off = fz * plane + (fy * row + ((fx << SH) + origin))
+            A.off = (unsigned)(__mul24((int)fzA, a.plane4) + (__mul24((int)fyA, a.row4) + (((int)fxA << SH) + a.origin4)));
+            B.off = (unsigned)(__mul24((int)fzB, a.plane4) + (__mul24((int)fyB, a.row4) + (((int)fxB << SH) + a.origin4)));
+            if (CHECK) {
+                A.off = A.in ? A.off : 0u;
+                B.off = B.in ? B.off : 0u;
+            }
+            A.tv = *reinterpret_cast<const float *>(tbase + toff);
+            B.tv = *reinterpret_cast<const float *>(tbase + toff + 4u * kTileX);
+        };
+        auto finish = [&](const Vox &p, float r, double &ss, double &st) {
+            const float sv = CHECK ? __uint_as_float(p.in ? __float_as_uint(r) : 0u) : r;
+            ss = __builtin_fma((double)sv, (double)sv, ss);
+            st = __builtin_fma((double)sv, (double)p.tv, st);
+        };
+        if constexpr (!PAIRS) {
+            // plain layout: 8-byte gathers of (x0, x1) at rows y0, y1 of the lower and the upper plane
+            auto accumulate = [&](const Vox &p, f32x2 lo0, f32x2 lo1, f32x2 up0, f32x2 up1, double &ss, double &st) {
+                const f32x2 p00 = p.wx * lo0, p01 = p.wx * lo1, p10 = p.wx * up0, p11 = p.wx * up1;
+                const f32x2 lower = {p00.x + p00.y, p01.x + p01.y}, upper = {p10.x + p10.y, p11.x + p11.y};
+                const f32x2 el = p.wy * lower, eu = p.wy * upper;
+                const f32x2 e = {el.x + el.y, eu.x + eu.y};
+                const f32x2 rz = p.wz * e;
+                finish(p, rz.x + rz.y, ss, st);
+            };
+            struct Taps { f32x2 r0, r1; };  // rows y0, y1 of one source plane, (x0, x1) each
+            auto plane = [&](unsigned off, bool upper) {
+                return Taps{gather_pair(rsrc, off, upper ? sPlane : 0u), gather_pair(rsrc, off, upper ? sBoth : sRow)};
+            };
+            Vox cA, cB;
+            prepare(z0, toff, cA, cB);
+            Taps aP = plane(cA.off, false), aQ = plane(cA.off, true), aR = aQ;
+            Taps bP = plane(cB.off, false), bQ = plane(cB.off, true), bR = bQ;
+            // One z step.  (lo, up, nx) name three register sets whose roles rotate from step to step, so the plane
+            // reuse -- the upper plane of this step is the lower plane of the next -- is a renaming, not a copy: a lane
+            // that did NOT move exactly one plane gathers its new lower plane INTO the set that held the upper one.
+            auto step = [&](int z, Taps &aLo, Taps &aUp, Taps &aNx, Taps &bLo, Taps &bUp, Taps &bNx) {
+                toff += tstep;
+                Vox nA, nB;
+                prepare(z, toff, nA, nB);
+                if (CHECK && REUSE) {  // out of the window: ride on the offset the plane reuse expects
+                    nA.off = nA.in ? nA.off : cA.off + sPlane;
+                    nB.off = nB.in ? nB.off : cB.off + sPlane;
+                }
+                aNx = plane(nA.off, true);
+                bNx = plane(nB.off, true);
+                Taps al, bl;
+                if (!REUSE) {
+                    al = plane(nA.off, false);
+                    bl = plane(nB.off, false);
+                }
+                accumulate(cA, aLo.r0, aLo.r1, aUp.r0, aUp.r1, ssA, stA);
+                accumulate(cB, bLo.r0, bLo.r1, bUp.r0, bUp.r1, ssB, stB);
+                if (REUSE) {
+                    // keep the (rare) re-gather BELOW the interpolation that still reads the upper plane (the empty asm
+                    // pins the four sums here): issued above it, the load needs a copy of the register set -- 4 moves
+                    // per voxel, measured in the ISA
+                    asm volatile("" : "+v"(ssA), "+v"(stA), "+v"(ssB), "+v"(stB) : : "memory");
+                    if (nA.off != cA.off + sPlane) aUp = plane(nA.off, false);
+                    if (nB.off != cB.off + sPlane) bUp = plane(nB.off, false);
+                } else {
+                    aUp = al;
+                    bUp = bl;
+                }
+                cA = nA;
+                cB = nB;
+            };
+            int z = z0 + 1;
+            for (; z + 2 < z1; z += 3) {
+                step(z, aP, aQ, aR, bP, bQ, bR);      // afterwards: lower = Q, upper = R
+                step(z + 1, aQ, aR, aP, bQ, bR, bP);  // lower = R, upper = P
+                step(z + 2, aR, aP, aQ, bR, bP, bQ);  // lower = P, upper = Q
+            }
+            for (; z < z1; ++z) {  // remainder (a z segment cut short by the volume): rotate by copying
+                step(z, aP, aQ, aR, bP, bQ, bR);
+                aP = aQ; aQ = aR; bP = bQ; bQ = bR;
+            }
+            accumulate(cA, aP.r0, aP.r1, aQ.r0, aQ.r1, ssA, stA);
+            accumulate(cB, bP.r0, bP.r1, bQ.r0, bQ.r1, ssB, stB);
+        } else {
+            // row-pair layout: one 16-byte gather = (y0 x0, y1 x0, y0 x1, y1 x1) of a plane
+            auto accumulate = [&](const Vox &p, f32x4 lo, f32x4 up, double &ss, double &st) {
+                const f32x2 lo_a = {lo.x, lo.y}, lo_b = {lo.z, lo.w}, up_a = {up.x, up.y}, up_b = {up.z, up.w};
+                const f32x2 cl = lo_a * p.wx.x + lo_b * p.wx.y;
+                const f32x2 cu = up_a * p.wx.x + up_b * p.wx.y;
+                const f32x2 el = p.wy * cl, eu = p.wy * cu;
+                const f32x2 e = {el.x + el.y, eu.x + eu.y};
+                const f32x2 rz = p.wz * e;
+                finish(p, rz.x + rz.y, ss, st);
+            };
+            Vox cA, cB;
+            prepare(z0, toff, cA, cB);
+            f32x4 aP = gather_quad(rsrc, cA.off, 0u), aQ = gather_quad(rsrc, cA.off, sPlane), aR = aQ;
+            f32x4 bP = gather_quad(rsrc, cB.off, 0u), bQ = gather_quad(rsrc, cB.off, sPlane), bR = bQ;
+            auto step = [&](int z, f32x4 &aLo, f32x4 &aUp, f32x4 &aNx, f32x4 &bLo, f32x4 &bUp, f32x4 &bNx) {
+                toff += tstep;
+                Vox nA, nB;
+                prepare(z, toff, nA, nB);
+                if (CHECK && REUSE) {
+                    nA.off = nA.in ? nA.off : cA.off + sPlane;
+                    nB.off = nB.in ? nB.off : cB.off + sPlane;
+                }
+                aNx = gather_quad(rsrc, nA.off, sPlane);
+                bNx = gather_quad(rsrc, nB.off, sPlane);
+                f32x4 al, bl;
+                if (!REUSE) {
+                    al = gather_quad(rsrc, nA.off, 0u);
+                    bl = gather_quad(rsrc, nB.off, 0u);
+                }
+                accumulate(cA, aLo, aUp, ssA, stA);
+                accumulate(cB, bLo, bUp, ssB, stB);
+                if (REUSE) {
+                    asm volatile("" : "+v"(ssA), "+v"(stA), "+v"(ssB), "+v"(stB) : : "memory");  // as in the plain layout
+                    if (nA.off != cA.off + sPlane) aUp = gather_quad(rsrc, nA.off, 0u);
+                    if (nB.off != cB.off + sPlane) bUp = gather_quad(rsrc, nB.off, 0u);
+                } else {
+                    aUp = al;
+                    bUp = bl;
+                }
+                cA = nA;
+                cB = nB;
+            };
+            int z = z0 + 1;
+            for (; z + 2 < z1; z += 3) {
+                step(z, aP, aQ, aR, bP, bQ, bR);
+                step(z + 1, aQ, aR, aP, bQ, bR, bP);
+                step(z + 2, aR, aP, aQ, bR, bP, bQ);
+            }
+            for (; z < z1; ++z) {
+                step(z, aP, aQ, aR, bP, bQ, bR);
+                aP = aQ; aQ = aR; bP = bQ; bQ = bR;
+            }
+            accumulate(cA, aP, aQ, ssA, stA);
+            accumulate(cB, bP, bQ, ssB, stB);
+        }
+    };
+    if (active) {
+        if (fast) run(std::false_type{});
+        else run(std::true_type{});
+    }
+    // Voxel A is a lane of one 64-wide workgroup of the one-voxel-per-lane decomposition, voxel B the same lane of the next
+    // one: the same shuffle tree on each, the same order over the waves, two publishes.
+    ssA = corr_wave_sum(ssA);
+    stA = corr_wave_sum(stA);
+    ssB = corr_wave_sum(ssB);
+    stB = corr_wave_sum(stB);
+    if (lane == 0) {
+        lds[wave] = ssA;
+        lds[kTileY + wave] = stA;
+        lds[2 * kTileY + wave] = ssB;
+        lds[3 * kTileY + wave] = stB;
+    }
+    __syncthreads();
+    double v0[2] = {0.0, 0.0}, v1[2] = {0.0, 0.0};
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int w = 0; w < kTileY; ++w) {
+                v0[h] += lds[h * 2 * kTileY + w];
+                v1[h] += lds[h * 2 * kTileY + kTileY + w];
+            }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int obx = 2 * bx + h;  // workgroup x index of the 64-wide decomposition
+        if (obx < old_grid_x)
+            corr_publish_as<kThreads>(obx + old_grid_x * (by + a.gy * bz), v0[h], v1[h], tail, lds, &last);
+    }
 }
 
 // dst[z+1][y+1][x+1] = (src[z][y][x], src[z][y+1][x]) with edge replication; y runs over [-1, sy-1].
@@ -296,21 +579,24 @@ __global__ __launch_bounds__(256) void pad_rowpair_kernel(float2 *__restrict__ d
         make_float2(pl[(size_t)x + (size_t)sx * y0], pl[(size_t)x + (size_t)sx * y1]);
 }
 
-// dst[z+1][y+1][x+1] = src[z][y][x]; border voxels replicate the nearest edge voxel.
+// dst[z+1][y+1][x+1] = src[z][y][x]; border voxels replicate the nearest edge voxel.  Rows are `pitch` floats apart (a
+// multiple of 4: 16-byte aligned rows); the 0-2 floats of padding at the end of a row repeat the edge voxel too.
 __global__ __launch_bounds__(256) void pad_replicate_kernel(float *__restrict__ dst, const float *__restrict__ src,
-                                                          int sx, int sy, int sz) {
+                                                          int sx, int sy, int sz, int pitch) {
     const int xp = blockIdx.x * 256 + threadIdx.x, yp = blockIdx.y, zp = blockIdx.z;
-    if (xp >= sx + 2) return;
+    if (xp >= pitch) return;
     const int x = min(max(xp - 1, 0), sx - 1), y = min(max(yp - 1, 0), sy - 1), z = min(max(zp - 1, 0), sz - 1);
-    dst[(size_t)xp + (size_t)(sx + 2) * ((size_t)yp + (size_t)(sy + 2) * zp)] =
+    dst[(size_t)xp + (size_t)pitch * ((size_t)yp + (size_t)(sy + 2) * zp)] =
         src[(size_t)x + (size_t)sx * ((size_t)y + (size_t)sy * z)];
 }
 
 }  // namespace
 
+long long PaddedSource::plain_pitch(Dims s) { return (s.nx + 2 + 3) / 4 * 4; }
+
 bool PaddedSource::eligible(Dims t, Dims s) {
     if (t.nx <= 0 || t.ny <= 0 || t.nz <= 0 || s.nx <= 0 || s.ny <= 0 || s.nz <= 0) return false;
-    const long long xp = s.nx + 2, yp = s.ny + 2, zp = s.nz + 2;
+    const long long xp = plain_pitch(s), yp = s.ny + 2, zp = s.nz + 2;
     // every byte offset fits 32 bits (the buffer's record count is a signed int: 2 GiB); both operands of each 24-bit
     // multiply fit 23 bits + sign; float32 holds every target index exactly
     return xp * yp * zp * 4 < (1ll << 31) && t.count() * 4 < (1ll << 32) && xp * yp * 4 < (1ll << 23) &&
@@ -326,10 +612,13 @@ void PaddedSource::build(const float *src, Dims d, hipStream_t s) {
     if (d.nx <= 0 || d.ny <= 0 || d.nz <= 0) throw Error(-1, "PaddedSource: empty volume");
     if (d.ny + 2 > 65535 || d.nz + 2 > 65535) throw Error(-1, "PaddedSource: volume exceeds launch limits");
     dims = d;
-    const size_t n = (size_t)(d.nx + 2) * (d.ny + 2) * (d.nz + 2);
+    pitch = plain_pitch(d);
+    // + 16 floats of slack behind the last row
+    const size_t n = (size_t)pitch * (d.ny + 2) * (d.nz + 2) + 16;
     if (data.size() < n) data.alloc(n);
-    dim3 grid((unsigned)div_up(d.nx + 2, 256), (unsigned)(d.ny + 2), (unsigned)(d.nz + 2));
-    hipLaunchKernelGGL(pad_replicate_kernel, grid, dim3(256), 0, s, data.get(), src, (int)d.nx, (int)d.ny, (int)d.nz);
+    dim3 grid((unsigned)div_up(pitch, 256), (unsigned)(d.ny + 2), (unsigned)(d.nz + 2));
+    hipLaunchKernelGGL(pad_replicate_kernel, grid, dim3(256), 0, s, data.get(), src, (int)d.nx, (int)d.ny, (int)d.nz,
+                       (int)pitch);
     MIL_HIP(hipGetLastError());
     has_pairs = row_pairs_fit(d);
     if (has_pairs) {
@@ -344,7 +633,7 @@ void PaddedSource::build(const float *src, Dims d, hipStream_t s) {
 
 namespace {
 
-// Which kernel serves this matrix best (measured at 512x512x256, tools/bench_corr.py --sweep; all three give the same
+// Which layout / reuse serves this matrix best (measured at 512x512x256, tools/bench_corr.py --sweep; all three give the same
 // sums).  The plane reuse of corr_padded_kernel skips a gather only when EVERY lane of a wave reuses, so what counts is
 // how often, per z step, some lane of a 64-wide wave crosses a source column, row or plane out of turn: the crossing rate
 // of one lane (|m2|, |m6|, |m10 - 1| per step) times the number of distinct phases the wave's lanes carry
@@ -352,11 +641,10 @@ namespace {
 //   < 0.08  plain layout + plane reuse           (translations, pure scales, rotations up to ~2 degrees)
 //   < 0.6   row pairs + plane reuse              (the usual registration matrix: a few degrees AND a few per cent)
 //   else    row pairs, both planes gathered      (large rotations)
-int g_forced_kernel = -1;  // test / profiling aid, corr_padded_force_kernel()
+int g_forced_kernel = -1;  // test / profiling aid, corr_padded_force_kernel(): 0-2 one voxel per lane, 3-5 two
 
-int pick_kernel(const float *m, bool has_pairs) {
+int pick_layout(const float *m, bool has_pairs) {
     if (!has_pairs) return 0;
-    if (g_forced_kernel >= 0 && g_forced_kernel <= 2) return g_forced_kernel;
     auto frac_dist = [](double v) { return std::fabs(v - std::nearbyint(v)); };
     auto phases = [&](double per_x) { return std::min(64.0, 1.0 + 64.0 * frac_dist(per_x)); };
     const double rate = std::fabs((double)m[2]) * phases(m[0]) + std::fabs((double)m[6]) * phases(m[4]) +
@@ -365,17 +653,26 @@ int pick_kernel(const float *m, bool has_pairs) {
     return rate < 0.6 ? 2 : 1;
 }
 
+// 0 plain + reuse | 1 row pairs | 2 row pairs + reuse: one voxel per lane; 3 / 4 / 5: the same with two voxels per lane
+// (needs a target width that is a multiple of 128).  Measured at 512 x 512 x 256 (tools/bench_corr.py, ms per evaluation):
+// the two-voxel form wins wherever the plane reuse mostly holds (identity 0.156 vs 0.171, 2 % scale 0.152 vs 0.157,
+// 3 deg + 2 % 0.191 vs 0.199); with both planes gathered every step (large rotations) the one-voxel form keeps fewer
+// cache lines per gather in flight and wins (45 deg: 0.500 vs 0.541).
+int pick_kernel(const float *m, bool has_pairs, bool wide) {
+    const int forced = g_forced_kernel;
+    if (forced >= 0 && forced <= 5) {
+        const int layout = forced % 3;
+        return ((layout == 0 || has_pairs) ? layout : 0) + ((forced >= 3 && wide) ? 3 : 0);
+    }
+    const int layout = pick_layout(m, has_pairs);
+    return layout + ((wide && layout != 1) ? 3 : 0);
+}
+
 }  // namespace
 
 void corr_padded_force_kernel(int kernel) { g_forced_kernel = kernel; }
 
-int corr_padded_pick_kernel(const Affine12 &m) {
-    const int forced = g_forced_kernel;
-    g_forced_kernel = -1;
-    const int k = pick_kernel(m.m, true);
-    g_forced_kernel = forced;
-    return k;
-}
+int corr_padded_pick_kernel(const Affine12 &m) { return pick_layout(m.m, true); }
 
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
                             hipStream_t s) {
@@ -388,23 +685,41 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
     const long long xp = src.dims.nx + 2, yp = src.dims.ny + 2, yp2 = src.dims.ny + 1, zp = src.dims.nz + 2;
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kStepsZ - 1) / kStepsZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    // the partials are those of the 64 x 4 x 16 decomposition whichever kernel runs
     const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
-    const int kernel = pick_kernel(a.m, src.has_pairs);
-    if (kernel != 0) {  // float2 volume [sz+2][sy+1][sx+2]
+    // two voxels per lane (x and x + 64): whole 128-wide workgroups only
+    const bool wide = a.tx % (2 * kTileX) == 0;
+    const int kernel = pick_kernel(a.m, src.has_pairs, wide);
+    const int layout = kernel % 3;
+    const int old_gx = (int)grid.x;
+    if (kernel >= 3) grid.x = (grid.x + 1) / 2;  // 128 x per workgroup
+    a.gx = (int)grid.x;
+    a.gy = (int)grid.y;
+    const size_t n_wg = (size_t)grid.x * grid.y * grid.z;
+    if (n_wg > 0x7fffffffu) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    grid = dim3((unsigned)n_wg);  // one-dimensional, decoded by corr_tile_of_block
+    if (layout != 0) {  // float2 volume [sz+2][sy+1][sx+2]
         a.row4 = (int)(8 * xp);
         a.plane4 = (int)(8 * xp * yp2);
         a.origin4 = (int)(8 * ((yp2 + 1) * xp + 1));
         a.bytes = (unsigned)(8 * xp * yp2 * zp);
-        if (kernel == 2)
-            hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a, tail);
+        const float *p = src.pairs.get();
+        switch (kernel) {
+            case 1: hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, p, a, tail); break;
+            case 2: hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, p, a, tail); break;
+            case 4: hipLaunchKernelGGL((corr_pair_kernel<true, false>), grid, dim3(kThreads), 0, s, target, p, a, tail, old_gx); break;
+            default: hipLaunchKernelGGL((corr_pair_kernel<true, true>), grid, dim3(kThreads), 0, s, target, p, a, tail, old_gx); break;
+        }
+    } else {            // float volume [sz+2][sy+2][pitch]
+        const long long pitch = src.pitch;
+        a.row4 = (int)(4 * pitch);
+        a.plane4 = (int)(4 * pitch * yp);
+        a.origin4 = (int)(4 * (pitch * yp + pitch + 1));
+        a.bytes = (unsigned)(4 * pitch * yp * zp);
+        if (kernel == 3)
+            hipLaunchKernelGGL((corr_pair_kernel<false, true>), grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail, old_gx);
         else
-            hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, src.pairs.get(), a, tail);
-    } else {            // float volume [sz+2][sy+2][sx+2]
-        a.row4 = (int)(4 * xp);
-        a.plane4 = (int)(4 * xp * yp);
-        a.origin4 = (int)(4 * (xp * yp + xp + 1));
-        a.bytes = (unsigned)(4 * xp * yp * zp);
-        hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail);
+            hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail);
     }
     MIL_HIP(hipGetLastError());
 }

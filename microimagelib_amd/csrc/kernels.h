@@ -110,7 +110,7 @@ void corr_sums_sync(const float *target, const float *src, Dims t_dims, Dims s_d
 
 // Source volume of the 3-D registration with a one-voxel replicated border -- the texture unit's clamp addressing
 // materialised in memory, so the cost kernels need neither index clamps nor edge selects (corr_padded.hip).  Held twice:
-// plain, [sz+2][sy+2][sx+2] floats, and as row pairs, [sz+2][sy+1][sx+2] float2 = (row y, row y+1), which turns the four
+// plain, [sz+2][sy+2][pitch >= sx+2] floats, and as row pairs, [sz+2][sy+1][sx+2] float2 = (row y, row y+1), which turns the four
 // taps of a source plane into ONE 16-byte gather.  corr_sums_padded_* pick the kernel per matrix; every choice returns
 // the same sums, bit for bit, as corr_sums_* on the unpadded volume.
 struct PaddedSource {
@@ -118,11 +118,14 @@ struct PaddedSource {
     DeviceBuffer<float> pairs;  // row-pair layout (absent when it would exceed the kernels' 32-bit offsets)
     bool has_pairs = false;
     Dims dims{0, 0, 0};  // unpadded extents
+    long long pitch = 0;  // row pitch of the plain layout in floats: sx + 2 rounded up to a multiple of 4
+    static long long plain_pitch(Dims source);
     static bool eligible(Dims target, Dims source);  // all byte offsets fit 32 bits
     static bool row_pairs_fit(Dims source);
     void build(const float *src, Dims dims, hipStream_t s);
 };
-// test / profiling aid: 0 plain + plane reuse | 1 row pairs | 2 row pairs + plane reuse | -1 (default) per matrix
+// test / profiling aid: 0 plain + plane reuse | 1 row pairs | 2 row pairs + plane reuse | 3-5 the same with two voxels
+// per lane | -1 (default) per matrix
 void corr_padded_force_kernel(int kernel);
 // host logic only: the kernel the per-matrix choice takes when both layouts are held (0 / 1 / 2 as above)
 int corr_padded_pick_kernel(const Affine12 &m);

@@ -144,7 +144,7 @@ class PaddedSource:
 
 def corr_padded_force_kernel(kernel: int = -1):
     """Test / profiling aid: pin the padded-source cost kernel (0 plain + plane reuse, 1 row pairs, 2 row pairs + plane
-    reuse); -1 restores the per-matrix choice."""
+    reuse, 3-5 the same with two voxels per lane); -1 restores the per-matrix choice."""
     _lib.load().mil_corr_padded_force_kernel(int(kernel))
 
 

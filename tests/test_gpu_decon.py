@@ -264,7 +264,13 @@ def test_full_size_libapi_vs_oracle_fixture(api):
     out, rec = api.decon_singleview(img_a, fi.psf_a(), int(g["iters"]))
     assert rec[0] == 1
     _check_fullsize(out, g, "sv")
-    out, rec = api.decon_dualview(img_a, img_b, fi.psf_a(), fi.psf_b(), int(g["iters"]))
+    # libapi.h passes ONE psfSize for both views: embed the 33x9x9 and 9x9x33 PSFs centred in a common 33x9x33 box
+    # (zeros around them; the centre voxel stays at s/2, so the OTFs are the same bits)
+    pa = np.zeros((33, 9, 33), dtype=f32)
+    pb = np.zeros((33, 9, 33), dtype=f32)
+    pa[:, :, 12:21] = fi.psf_a()
+    pb[12:21, :, :] = fi.psf_b()
+    out, rec = api.decon_dualview(img_a, img_b, pa, pb, int(g["iters"]))
     _check_fullsize(out, g, "dv")
 
 

@@ -202,7 +202,7 @@ def test_padded_cost_kernel_is_bit_identical(dev):
     pad = dev.PaddedSource(src)
     for i, m in enumerate(g["mats"]):
         a = dev.corr_sums(tgt, src, m)
-        for kern in (-1, 0, 1, 2):  # per-matrix choice, then each of the three padded-source kernels
+        for kern in (-1, 0, 1, 2, 3, 4, 5):  # per-matrix choice, then each padded-source kernel (3-5: two voxels per lane)
             dev.corr_padded_force_kernel(kern)
             b = dev.corr_sums(tgt, pad, m)
             assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"golden matrix {i}, kernel {kern}"
@@ -213,7 +213,10 @@ def test_padded_cost_kernel_is_bit_identical(dev):
     pad.close()
     rng = np.random.default_rng(7)
     for shape_s, shape_t in (((17, 23, 70), (19, 21, 66)), ((5, 3, 2), (6, 4, 3)), ((1, 1, 1), (3, 3, 3)),
-                             ((33, 40, 130), (33, 40, 130))):
+                             ((33, 40, 130), (33, 40, 130)),
+                             # target widths that are multiples of 128: the two-voxels-per-lane kernels (3-5), with
+                             # ragged y / z blocks and a source of another size
+                             ((17, 23, 70), (19, 21, 128)), ((9, 40, 300), (18, 10, 256))):
         src = rng.standard_normal(shape_s).astype(f32)
         tgt = rng.standard_normal(shape_t).astype(f32)
         ds, dt = T(src), T(tgt)
@@ -233,7 +236,7 @@ def test_padded_cost_kernel_is_bit_identical(dev):
         mats.append(np.full(12, np.nan, dtype=f32))
         for i, m in enumerate(mats):
             a = dev.corr_sums(dt, ds, m)
-            for kern in (-1, 0, 1, 2):
+            for kern in (-1, 0, 1, 2, 3, 4, 5):
                 dev.corr_padded_force_kernel(kern)
                 b = dev.corr_sums(dt, pad, m)
                 assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"{shape_s} matrix {i}, kernel {kern}"

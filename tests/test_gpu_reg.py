@@ -281,7 +281,7 @@ def test_full_size_cost_and_resample_vs_oracle_fixture(dev, api):
         wss, wst = g["corr_sums"][i]
         ss, st = dev.corr_sums(t_dev, s_dev, m)
         assert abs(ss - wss) <= 1e-12 * wss and abs(st - wst) <= 1e-12 * wss, (i, ss, st, wss, wst)
-        for kern in (-1, 0, 1, 2):
+        for kern in (-1, 0, 1, 2, 3, 4, 5):
             dev.corr_padded_force_kernel(kern)
             assert dev.corr_sums(t_dev, pad, m) == (ss, st), f"matrix {i}, padded kernel {kern}"
     dev.corr_padded_force_kernel(-1)
@@ -357,7 +357,7 @@ def test_full_size_registration_properties(dev):
     rot20[[3, 7]] = (90.0, -80.0)
     for m in (ident, rot, rot20):
         want = dev.corr_sums(ms, ms, m)
-        for kern in (-1, 0, 1, 2):
+        for kern in (-1, 0, 1, 2, 3, 4, 5):
             dev.corr_padded_force_kernel(kern)
             assert dev.corr_sums(ms, pad, m) == want, f"kernel {kern}"
     dev.corr_padded_force_kernel(-1)

@@ -14,7 +14,7 @@ src = torch.rand(shape, device="cuda", generator=g)
 general = "--general" in sys.argv
 source = src if general else mdev.PaddedSource(src)
 for a in sys.argv:
-    if a.startswith("--kernel="):  # 0 plain + reuse | 1 row pairs | 2 row pairs + reuse (default: per matrix)
+    if a.startswith("--kernel="):  # 0 plain + reuse | 1 row pairs | 2 row pairs + reuse, +3: two voxels per lane (default: per matrix)
         mdev.corr_padded_force_kernel(int(a.split("=")[1]))
 print("kernel:", "corr_kernel (general)" if general else "padded-source kernels " + " ".join(sys.argv[1:]))
 
