@@ -24,7 +24,10 @@ extern "C" {
 const char *mil_version(void);
 int mil_device_count(void);
 int mil_set_device(int device);               /* cudaSetDevice(deviceNum), src/api_decon.cpp:102 */
-int mil_snap_transform_size(int n);           /* snapTransformSize, src/api_subfunc.cu:57-87 */
+int mil_snap_transform_size(int n);
+/* Device buffers freed inside the library are kept for the next call of the same size (the reference re-allocates ~2 GB per
+ * libapi.h call); this returns them to the driver.  Returns the number of bytes released.  MIL_POOL_MB caps the cache. */
+size_t mil_release_cached_memory(void);           /* snapTransformSize, src/api_subfunc.cu:57-87 */
 
 /* ---- RL element-wise kernels (in place) ----------------------------------- */
 int mil_rl_ratio(float *d_T, const float *d_A, size_t n, void *stream);               /* div3Dgpu  src/api_subfunc.cu:333 */

@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <vector>
 
 #include "../../include/libapi.h"
 #include "cpu_decon.h"
@@ -60,6 +62,12 @@ int resolve_mode(int requested, size_t bytes_needed, bool verbose) {
         const size_t cap_b = (size_t)atoll(cap) << 20;
         if (cap_b < free_b) free_b = cap_b;
     }
+    if (free_b <= bytes_needed && !getenv("MIL_DECON_FREE_MB_CAP")) {
+        // what earlier calls left cached (device pool, engine, OTFs) is ours to give back before giving up on the GPU
+        decon_cache_drop();
+        pool_release_all();
+        MIL_HIP(hipMemGetInfo(&free_b, &total_b));
+    }
     if (free_b > bytes_needed) {
         if (verbose) printf("\t... GPU memory is sufficient, processing in efficient mode !!!\n");
         return 1;
@@ -113,21 +121,97 @@ void download_volume(float *h_dst, float *d_src, float *d_stage, const Geometry 
     MIL_HIP(hipStreamSynchronize(s));
 }
 
-// OTF + back-projector OTF for one view (reference src/api_decon.cpp:211-223).
-void make_otfs(DeconEngine &eng, float2 *d_otf, float2 *d_otf_bp, float *d_psf_stage, const float *h_psf,
-               const float *h_psf_bp, bool unmatch, const Geometry &g) {
-    hipStream_t s = eng.stream();
-    MIL_HIP(hipMemcpyAsync(d_psf_stage, h_psf, g.n_psf * sizeof(float), hipMemcpyHostToDevice, s));
-    eng.gen_otf(d_otf, d_psf_stage, g.psf, false);
-    if (unmatch) {
-        MIL_HIP(hipMemcpyAsync(d_psf_stage, h_psf_bp, g.n_psf * sizeof(float), hipMemcpyHostToDevice, s));
-        eng.gen_otf(d_otf_bp, d_psf_stage, g.psf, false);
-    } else {
-        eng.gen_otf(d_otf_bp, d_psf_stage, g.psf, true);  // matched back projector = flipped PSF
+// What a libapi.h deconvolution call keeps for the next one (the reference rebuilds all of it per call,
+// src/api_decon.cpp:198-223: plans, work areas and two to four OTFs): the engine of the last (device, box) with its tables
+// and scratch, and the OTFs it made, found again by comparing the PSF bytes.  A time-lapse batch calls with the same box
+// and the same PSFs for every time point.  Results are those of an uncached call, bit for bit (same kernels on the
+// same data); MIL_DECON_CACHE=0 disables it, mil_release_cached_memory() drops it.
+struct DeconCache {
+    struct Otf {
+        std::vector<float> psf;  // host copy: a hit is a full comparison, not a hash match
+        Dims dims;
+        bool flip;
+        DeviceBuffer<float2> buf;
+        unsigned long long stamp;
+    };
+    std::mutex mu;
+    int device = -1;
+    Dims box{0, 0, 0};
+    std::unique_ptr<DeconEngine> eng;
+    std::vector<std::unique_ptr<Otf>> otfs;
+    unsigned long long clock = 0;
+    void drop() {
+        otfs.clear();
+        eng.reset();
+        device = -1;
     }
+};
+
+DeconCache &decon_cache() {
+    static DeconCache *c = new DeconCache();  // never destroyed: see devpool.cpp
+    return *c;
+}
+
+bool cache_enabled() {
+    const char *v = getenv("MIL_DECON_CACHE");
+    return !(v && v[0] == '0');
+}
+
+DeconEngine &cached_engine(DeconCache &c, int device, Dims box) {
+    if (!c.eng || c.device != device || c.box != box) {
+        c.drop();
+        c.eng.reset(new DeconEngine(box, nullptr));
+        c.device = device;
+        c.box = box;
+    }
+    return *c.eng;
+}
+
+// OTF of (psf, flip) for the cached engine: reused when the same PSF bytes were seen before, made otherwise.
+const float2 *cached_otf(DeconCache &c, DeconEngine &eng, const float *h_psf, bool flip, float *d_psf_stage,
+                         const Geometry &g) {
+    constexpr size_t kMaxOtfs = 8;  // two views x (OTF, back projector) x two PSF sets
+    for (auto &o : c.otfs)
+        if (o->flip == flip && o->dims == g.psf && std::memcmp(o->psf.data(), h_psf, g.n_psf * sizeof(float)) == 0) {
+            o->stamp = ++c.clock;
+            return o->buf.get();
+        }
+    if (c.otfs.size() >= kMaxOtfs) {  // evict the least recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < c.otfs.size(); ++i)
+            if (c.otfs[i]->stamp < c.otfs[lru]->stamp) lru = i;
+        eng.synchronize();
+        c.otfs.erase(c.otfs.begin() + (long)lru);
+    }
+    std::unique_ptr<DeconCache::Otf> o(new DeconCache::Otf());
+    o->psf.assign(h_psf, h_psf + g.n_psf);
+    o->dims = g.psf;
+    o->flip = flip;
+    o->buf.alloc(eng.spectrum_count());
+    o->stamp = ++c.clock;
+    MIL_HIP(hipMemcpyAsync(d_psf_stage, h_psf, g.n_psf * sizeof(float), hipMemcpyHostToDevice, eng.stream()));
+    eng.gen_otf(o->buf.get(), d_psf_stage, g.psf, flip);
+    eng.synchronize();  // d_psf_stage is reused by the next OTF
+    c.otfs.push_back(std::move(o));
+    return c.otfs.back()->buf.get();
+}
+
+// OTF + back-projector OTF for one view (reference src/api_decon.cpp:211-223): matched back projector = flipped PSF.
+void view_otfs(DeconCache &c, DeconEngine &eng, const float2 *&otf, const float2 *&otf_bp, float *d_psf_stage,
+               const float *h_psf, const float *h_psf_bp, bool unmatch, const Geometry &g) {
+    otf = cached_otf(c, eng, h_psf, false, d_psf_stage, g);
+    otf_bp = unmatch ? cached_otf(c, eng, h_psf_bp, false, d_psf_stage, g) : cached_otf(c, eng, h_psf, true, d_psf_stage, g);
 }
 
 }  // namespace
+
+namespace mil {
+void decon_cache_drop() {
+    DeconCache &c = decon_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.drop();
+}
+}  // namespace mil
 
 extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSize, float *h_psf,
                                 unsigned int *psfSize, bool flagConstInitial, int itNumForDecon, int deviceNum,
@@ -161,14 +245,16 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         deconRecords[0] = (float)mode;
         const double t_init = now_s();
 
-        DeconEngine eng(g.box, nullptr);
+        DeconCache &cache = decon_cache();
+        std::lock_guard<std::mutex> lock(cache.mu);
+        if (!cache_enabled()) cache.drop();
+        DeconEngine &eng = cached_engine(cache, deviceNum, g.box);
         hipStream_t s = eng.stream();
         DeviceBuffer<float> dA(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
-        const size_t n_spec = eng.spectrum_count();  // backend-private OTF size
-        DeviceBuffer<float2> dOtf(n_spec), dOtfBp(n_spec);
         deconRecords[2] = free_mb();
 
-        make_otfs(eng, dOtf, dOtfBp, dPsf, h_psf, h_psf_bp, flagUnmatch, g);
+        const float2 *dOtf, *dOtfBp;
+        view_otfs(cache, eng, dOtf, dOtfBp, dPsf, h_psf, h_psf_bp, flagUnmatch, g);
         upload_volume(dA, dStage, h_img, g, s);
         eng.init_single(dA, dE, flagConstInitial);
         const double t_loop = now_s();
@@ -185,6 +271,7 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         deconRecords[7] = (float)(t_loop - t_init);
         deconRecords[8] = (float)(t_done - t_loop);
         deconRecords[9] = (float)(t_end - t_start);
+        if (!cache_enabled()) cache.drop();
         return 0;
     });
 }
@@ -220,15 +307,17 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         deconRecords[0] = (float)mode;
         const double t_init = now_s();
 
-        DeconEngine eng(g.box, nullptr);
+        DeconCache &cache = decon_cache();
+        std::lock_guard<std::mutex> lock(cache.mu);
+        if (!cache_enabled()) cache.drop();
+        DeconEngine &eng = cached_engine(cache, deviceNum, g.box);
         hipStream_t s = eng.stream();
         DeviceBuffer<float> dA(g.n_box), dB(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
-        const size_t n_spec = eng.spectrum_count();  // backend-private OTF size
-        DeviceBuffer<float2> dOtf1(n_spec), dOtf2(n_spec), dOtfBp1(n_spec), dOtfBp2(n_spec);
         deconRecords[2] = free_mb();
 
-        make_otfs(eng, dOtf1, dOtfBp1, dPsf, h_psf1, h_psf_bp1, flagUnmatch, g);  // reference :522-534
-        make_otfs(eng, dOtf2, dOtfBp2, dPsf, h_psf2, h_psf_bp2, flagUnmatch, g);  // :535-547
+        const float2 *dOtf1, *dOtfBp1, *dOtf2, *dOtfBp2;
+        view_otfs(cache, eng, dOtf1, dOtfBp1, dPsf, h_psf1, h_psf_bp1, flagUnmatch, g);  // reference :522-534
+        view_otfs(cache, eng, dOtf2, dOtfBp2, dPsf, h_psf2, h_psf_bp2, flagUnmatch, g);  // :535-547
         upload_volume(dA, dStage, h_img1, g, s);
         if (g.padded) MIL_HIP(hipStreamSynchronize(s));  // dStage is reused for the second view
         upload_volume(dB, dStage, h_img2, g, s);
@@ -247,6 +336,7 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         deconRecords[8] = (float)(t_done - t_loop);
         deconRecords[9] = (float)(t_end - t_start);
         if (verbose) printf("\t... deconvolution done !!! \n");
+        if (!cache_enabled()) cache.drop();
         return 0;
     });
 }

@@ -80,6 +80,11 @@ int mil_set_device(int device) {
 
 int mil_snap_transform_size(int n) { return snap_transform_size(n); }
 
+size_t mil_release_cached_memory(void) {
+    decon_cache_drop();
+    return pool_release_all();
+}
+
 int mil_rl_ratio(float *d_T, const float *d_A, size_t n, void *stream) {
     return guarded("mil_rl_ratio", [&] { k::rl_ratio(d_T, d_A, n, as_stream(stream)); return 0; });
 }

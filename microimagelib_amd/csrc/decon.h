@@ -23,6 +23,9 @@ namespace mil {
 // snapTransformSize, reference src/api_subfunc.cu:57-87.
 int snap_transform_size(int n);
 
+// Drops what the libapi.h deconvolution entry points keep between calls (engine, OTFs): api_decon.cpp.
+void decon_cache_drop();
+
 class Fft3D {
 public:
     Fft3D(Dims box, hipStream_t stream);

@@ -39,6 +39,11 @@ struct Dims {
 
 inline long long div_up(long long a, long long b) { return (a + b - 1) / b; }
 
+// Device allocations go through a pool that keeps freed blocks for the next call of the same size (devpool.cpp).
+void *pool_alloc(size_t bytes);
+void pool_free(void *p) noexcept;
+size_t pool_release_all();  // hipFree everything cached; returns the bytes given back
+
 // RAII device buffer.
 template <class T>
 class DeviceBuffer {
@@ -55,11 +60,11 @@ public:
     }
     void alloc(size_t n) {
         release();
-        if (n) MIL_HIP(hipMalloc((void **)&p_, n * sizeof(T)));
+        if (n) p_ = static_cast<T *>(pool_alloc(n * sizeof(T)));
         n_ = n;
     }
     void release() {
-        if (p_) (void)hipFree(p_);
+        if (p_) pool_free(p_);
         p_ = nullptr;
         n_ = 0;
     }

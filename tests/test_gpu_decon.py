@@ -121,6 +121,38 @@ def test_auto_mode_ladder(api, monkeypatch):
     assert rec[0] == 1 and rel_err(out, g["expected"]) < RTOL
 
 
+def test_cached_calls_are_bit_identical(api, monkeypatch):
+    """The entry points keep the engine and the OTFs of the last (device, box) for the next call (csrc/api_decon.cpp,
+    DeconCache) and device buffers in a pool: a repeated call, a call after other boxes / other PSFs were served, and a
+    call with the cache switched off all return the same bits."""
+    g = np.load(os.path.join(GOLD, "decon_sv_small.npz"))
+    d = np.load(os.path.join(GOLD, "decon_dv_small.npz"))
+    it = int(g["iters"])
+    api.release_cached_memory()
+    cold, _ = api.decon_singleview(g["img"], g["psf"], it)             # builds engine + OTFs
+    warm, _ = api.decon_singleview(g["img"], g["psf"], it)             # everything cached
+    assert np.array_equal(cold.view(np.uint32), warm.view(np.uint32))
+    assert rel_err(warm, g["expected"]) < RTOL
+    other = do.gaussian_psf((9, 9, 9), (1.0, 2.0, 1.5))
+    o1, _ = api.decon_singleview(g["img"], other, it)                  # same box, new PSF: OTF miss
+    assert rel_err(o1, do.decon_singleview(g["img"], other, it)) < RTOL
+    dv1, _ = api.decon_dualview(d["img1"], d["img2"], d["psf1"], d["psf2"], int(d["iters"]))
+    big = np.load(os.path.join(GOLD, "decon_sv_psf_eq_fft.npz"))
+    b1, _ = api.decon_singleview(big["img"], big["psf"], int(big["iters"]))  # another box: engine replaced
+    assert rel_err(b1, big["expected"]) < RTOL
+    again, _ = api.decon_singleview(g["img"], g["psf"], it)
+    assert np.array_equal(cold.view(np.uint32), again.view(np.uint32))
+    out = np.empty_like(g["img"])
+    same, _ = api.decon_singleview(g["img"], g["psf"], it, out=out)     # caller-owned output buffer
+    assert same is out and np.array_equal(cold.view(np.uint32), out.view(np.uint32))
+    monkeypatch.setenv("MIL_DECON_CACHE", "0")
+    nocache, _ = api.decon_singleview(g["img"], g["psf"], it)
+    dv2, _ = api.decon_dualview(d["img1"], d["img2"], d["psf1"], d["psf2"], int(d["iters"]))
+    assert np.array_equal(cold.view(np.uint32), nocache.view(np.uint32))
+    assert np.array_equal(dv1.view(np.uint32), dv2.view(np.uint32))
+    assert api.release_cached_memory() >= 0
+
+
 def test_memory_mode_2_runs_as_mode_1(api):
     g = np.load(os.path.join(GOLD, "decon_sv_psf_eq_fft.npz"))
     out, rec = api.decon_singleview(g["img"], g["psf"], 2, gpu_mem_mode=2)
