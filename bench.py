@@ -99,6 +99,8 @@ def main():
     # first 5 steps after idle, 1.02 ms after 50, 1.01 ms after 100).  A fixed number of untimed steps before the W
     # warm-up steps brings it to the sustained state a long deconvolution runs in, whatever W the caller picks.
     ap.add_argument("--clock-warm-steps", type=int, default=50)
+    ap.add_argument("--batch-time-points-per-gpu", type=int, default=2,
+                    help="time points per GPU of the config-5 figure in `extra` (register + joint RL + MIP); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4, help="RL iterations of the single-thread CPU baseline (~3 s each)")
@@ -304,6 +306,42 @@ def main():
                 "rl_update_kernel_hbm_frac": upd_frac,
             },
         }
+
+    # ---- supplementary, every N: BASELINE.json configs[4], the time-lapse batch ------------
+    # Each rank registers view B to view A (regMode 3: every time point on its own, reg3d affMethod 6 as the batch
+    # hard-codes), deconvolves the pair jointly (20 iterations) and projects; the XY MIPs are gathered to rank 0 (the
+    # only exchange).  Views resident in HBM -- the TIFF-inclusive form is tools/bench_batch.py --tiff.
+    if args.batch_time_points_per_gpu > 0 and not args.no_extra:
+        from microimagelib_amd import batch
+        c2, s2 = np.cos(np.deg2rad(2.0)), np.sin(np.deg2rad(2.0))
+        lin2 = np.array([[c2, 0, -s2], [0, 1, 0], [s2, 0, c2]])
+        centre2 = np.array([SHAPE[2] / 2, SHAPE[1] / 2, SHAPE[0] / 2])
+        known2 = np.concatenate([lin2, (centre2 - lin2 @ centre2 + np.array([3.0, -2.0, 1.0]))[:, None]],
+                                axis=1).astype(np.float32).reshape(12)
+        view_b = mdev.affine_resample(synth_volume(torch, SHAPE, (2.5, 2.5, 6.0), seed=100 + rank), known2, SHAPE)  # same object as view A, other PSF, displaced by 2 deg + shift
+        pipe = batch.FusionPipeline(SHAPE, psf_a, psf_b, iters=20)
+        n_tp = args.batch_time_points_per_gpu * world
+        pol = lambda: batch.RegPolicy(reg_mode=3, reg_choice=2, aff_method=6, ftol=1e-4, it_limit=3000)
+        run = lambda tps: batch.run_sharded(tps, lambda t: (img_a, view_b), pipe.fuse_pair, pol(), pipe.reg_fn,
+                                            pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev)
+        run(list(range(world)))  # warm-up: one time point per rank
+        fence()
+        tb = time.perf_counter()
+        stack = run(list(range(n_tp)))
+        fence()
+        batch_s = time.perf_counter() - tb
+        if distributed:
+            tt = torch.tensor([batch_s], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            batch_s = float(tt.item())
+        if rank == 0:
+            result["extra"]["batch_config5"] = {
+                "workload": "spimFusionBatch loop, regMode 3: reg3d (affMethod 6) + joint dual-view RL (20 it) + XY MIP per "
+                            "time point, 512x512x256, views resident in HBM, MIP stack gathered to rank 0",
+                "time_points": n_tp, "time_points_per_s": round(n_tp / batch_s, 3), "elapsed_s": round(batch_s, 3),
+                "mip_stack": list(stack.shape)}
+        pipe.close()
+        del view_b, pipe
 
     # ---- supplementary: dual view + registration (N = 1 only) ---------------------------
     if world == 1 and not args.no_extra:

@@ -241,9 +241,13 @@ def gettifinfo(path: str):
     return int(bits), (int(size[0]), int(size[1]), int(size[2]))
 
 
-def readtifstack(path: str) -> np.ndarray:
+def readtifstack(path: str, out=None) -> np.ndarray:
+    """``readtifstack`` (reference include/libapi.h); `out`: a caller-owned float32 [z][y][x] buffer of the stack's size."""
     _, (sx, sy, sz) = gettifinfo(path)
-    out = np.empty((sz, sy, sx), dtype=np.float32)
+    if out is None:
+        out = np.empty((sz, sy, sx), dtype=np.float32)
+    elif out.dtype != np.float32 or out.shape != (sz, sy, sx) or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float32 array of the stack's shape")
     size = (C.c_uint * 3)()
     _lib.load().readtifstack(_fp(out), path.encode(), size)
     return out

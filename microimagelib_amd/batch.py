@@ -15,9 +15,10 @@ path; the only exchange is
     (12 floats), mirroring "register one, apply to all" (:719-751);
   * the final gather of the per-time-point XY maximum-intensity projections to rank 0.
 
-``regMode 2`` carries a loop dependence between time points: on several ranks the chain of
-registrations runs on rank 0, which posts each matrix to the rank owning the time point
-(12 + 11 floats, point to point); resampling, deconvolution and MIPs stay sharded.  All volume arithmetic happens in ``libapi.so``; this module is host logic.
+``regMode 2`` carries a loop dependence between time points: on several ranks the chain state
+(two matrices, 24 floats) is passed from the owner of one time point to the owner of the next, point
+to point; each owner registers, hands the state on, then deconvolves -- registrations serial, everything
+else overlapped (``_run_chained``).  All volume arithmetic happens in ``libapi.so``; this module is host logic.
 """
 from __future__ import annotations
 
@@ -176,48 +177,39 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
 
 
 def _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group):
-    """regMode 2 on several ranks.  The matrix chain (running 0.8 / 0.2 average, fall-back to the previous matrix,
-    src/spim_fusion_batch.cpp:786-808) is inherently sequential, so rank 0 walks it over ALL time points in order and
-    posts each result -- 12 matrix floats + 11 record floats, point to point -- to the rank that owns the time point;
-    the owner applies the matrix (regChoice 0: the same resample kernel with the same matrix as the registration's own
-    final resample, hence the same volume) and runs the joint deconvolution.  Registration stays serial, everything
-    after it is sharded; results are identical to the single-rank run."""
+    """regMode 2 on several ranks: a token ring.  The matrix chain (running 0.8 / 0.2 average, fall-back to the previous
+    matrix, src/spim_fusion_batch.cpp:786-808) is inherently sequential: time point i cannot register before i - 1 has.
+    The chain STATE -- the weighted and the previous matrix, 24 floats -- travels from the owner of time point i - 1 to the
+    owner of time point i (ranks own time points round-robin); the owner, which has already loaded its pair, registers
+    it, passes the state on and only then deconvolves.  So every pair is loaded once, no volume ever crosses ranks, every
+    rank does the same kind of work, and the deconvolution of time point i overlaps with the registration of i + 1 on
+    the next rank.  Registrations stay serial (the reference's semantics), results equal the single-rank run's.
+    Throughput bound with registration share r of a time point: 1 / (r + (1 - r) / N) of one GPU's."""
     rank, world = _world(group)
-    owner = {t: i % world for i, t in enumerate(time_points)}
+    n = len(time_points)
     local: Dict[int, torch.Tensor] = {}
-    pending = []
-    if rank == 0:
-        for i, t in enumerate(time_points):
-            a, b = load_pair(t)
-            b_reg, tmx, rec = register_pair(policy, reg_fn, check_fn, a, b, first=(i == 0))
-            tmx = np.asarray(tmx, dtype=np.float32).reshape(12)
-            rec = np.asarray(rec, dtype=np.float32).reshape(-1)[:11]
-            if owner[t] == 0:
-                decon, mip = fuse_pair(a, b_reg, t)
-                local[t] = mip
-                if sink is not None:
-                    sink(t, decon, tmx, rec)
-            else:
-                msg = torch.zeros(23, dtype=torch.float32, device=device)
-                msg[:12].copy_(torch.from_numpy(tmx))
-                msg[12:12 + rec.size].copy_(torch.from_numpy(rec))
-                pending.append((dist.isend(msg, dst=owner[t], group=group), msg))  # keep msg alive until sent
-        for req, _ in pending:
-            req.wait()
-    else:
-        apply = RegPolicy(reg_mode=0, reg_choice=0, aff_method=policy.aff_method, ftol=policy.ftol,
-                          it_limit=policy.it_limit, cost_bar=policy.cost_bar)
-        for t in shard_time_points(time_points, rank, world):
-            msg = torch.zeros(23, dtype=torch.float32, device=device)
-            dist.recv(msg, src=0, group=group)
-            got = msg.cpu().numpy()
-            apply.i_tmx = got[:12].copy()
-            a, b = load_pair(t)
-            b_reg, _, _ = register_pair(apply, reg_fn, check_fn, a, b, first=False)
-            decon, mip = fuse_pair(a, b_reg, t)
-            local[t] = mip
-            if sink is not None:
-                sink(t, decon, got[:12].copy(), got[12:].copy())
+    sends = []
+    for i, t in enumerate(time_points):
+        if i % world != rank:
+            continue
+        a, b = load_pair(t)  # before the token arrives: overlaps with the registrations upstream
+        if i > 0:
+            state = torch.zeros(24, dtype=torch.float32, device=device)
+            dist.recv(state, src=(i - 1) % world, group=group)
+            got = state.cpu().numpy()
+            policy.weighted, policy.previous = got[:12].copy(), got[12:].copy()
+        b_reg, tmx, rec = register_pair(policy, reg_fn, check_fn, a, b, first=(i == 0))
+        if i + 1 < n:
+            state = torch.zeros(24, dtype=torch.float32, device=device)
+            state[:12].copy_(torch.from_numpy(np.asarray(policy.weighted, dtype=np.float32).reshape(12)))
+            state[12:].copy_(torch.from_numpy(np.asarray(policy.previous, dtype=np.float32).reshape(12)))
+            sends.append((dist.isend(state, dst=(i + 1) % world, group=group), state))  # keep the tensor alive
+        decon, mip = fuse_pair(a, b_reg, t)
+        local[t] = mip
+        if sink is not None:
+            sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
+    for req, _ in sends:
+        req.wait()
     return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
 
 

@@ -119,23 +119,35 @@ def test_register_once_apply_to_all_two_ranks(tmp_path):
 
 @pytest.mark.timeout(120)
 def test_chained_mode_two_ranks_matches_single_rank(tmp_path):
-    """regMode 2: rank 0 walks the matrix chain over all time points and posts each result to the owner, which applies
-    it (regChoice 0); matrices and MIP stack equal the single-rank run."""
+    """regMode 2: the chain state travels from owner to owner (token ring); every rank registers ITS time points, in
+    global order, each pair is loaded and registered exactly once; matrices and MIP stack equal the single-rank run."""
     r0, r1 = _run(tmp_path, reg_mode=2)
     assert r0["err"] is None and r1["err"] is None
-    # rank 0 registered every time point in order: first with the configured scheme, then chained (regChoice 2 from
-    # the running average)
-    regs = [e for e in r0["log"] if e[1] != 0]
-    assert [e[0] for e in regs] == [3, 4, 5, 6, 7]
-    assert regs[0] == [3, 2, False] and all(e == [t, 2, True] for e, t in zip(regs[1:], [4, 5, 6, 7]))
-    # rank 1 only applied what it was sent
-    assert [e[:2] for e in r1["log"]] == [[4, 0], [6, 0]] and all(e[2] for e in r1["log"])
+    # time points 3, 5, 7 on rank 0 and 4, 6 on rank 1: the first with the configured scheme and no input matrix, the
+    # others chained (regChoice 2 starting from the running average they were handed)
+    assert r0["log"] == [[3, 2, False], [5, 2, True], [7, 2, True]]
+    assert r1["log"] == [[4, 2, True], [6, 2, True]]
     assert sorted(int(t) for t in r0["sunk"]) == [3, 5, 7] and sorted(int(t) for t in r1["sunk"]) == [4, 6]
     (tmp_path / "single").mkdir()
     (s0,) = _run(tmp_path / "single", reg_mode=2, world=1)
     merged = {**r0["sunk"], **r1["sunk"]}
     assert merged == s0["sunk"]
     assert r0["stack"] == s0["stack"] == [31.0, 41.0, 51.0, 61.0, 71.0] and r1["stack"] is None
+
+
+@pytest.mark.timeout(120)
+def test_chained_mode_three_ranks_carries_the_running_average(tmp_path):
+    """The state handed on is the reference's: weighted = 0.8 * weighted + 0.2 * result (double arithmetic stored as
+    float), previous = result -- checked through the start matrices a three-rank ring registers from."""
+    rs = _run(tmp_path, reg_mode=2, world=3)
+    (tmp_path / "single").mkdir()
+    (s0,) = _run(tmp_path / "single", reg_mode=2, world=1)
+    merged = {}
+    for r in rs:
+        assert r["err"] is None
+        merged.update(r["sunk"])
+    assert merged == s0["sunk"] and rs[0]["stack"] == s0["stack"]
+    assert [len(r["log"]) for r in rs] == [2, 2, 1]  # 5 time points dealt 3, 4, 5, 6, 7 -> ranks 0, 1, 2, 0, 1
 
 
 def test_fallback_ladder_matches_reference():

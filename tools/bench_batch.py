@@ -7,8 +7,11 @@
 Every time point = register view B to view A (reg3d regChoice 2, affMethod 6 as the batch hard-codes,
 src/spim_fusion_batch.cpp:557), joint dual-view RL, XY maximum-intensity projection; afterwards the MIP stack is
 gathered to rank 0 (the only exchange).  Time points are dealt round-robin over the ranks (microimagelib_amd/batch.py).
-Prints ONE JSON line: time points/s over all ranks and the per-stage split of rank 0.  With --host the views start in
-pinned host memory and the result goes back to it, as the reference's loop moves them (TIFF decode excluded).
+Prints ONE JSON line: time points/s over all ranks, the per-stage split of rank 0 and the MIP-gather time.  With --host
+the views start in pinned host memory and the result goes back to it (TIFF decode excluded).  With --tiff DIR every rank
+READS its time points from 16-bit TIFF stacks on disk and WRITES the deconvolved 16-bit stack back inside the timed region,
+through the library's own codec (readtifstack / writetifstack, the reference's I/O path: src/spim_fusion_batch.cpp:640-700,
+:900-930) -- the honest form of config 5 on a shared host.
 """
 import argparse
 import json
@@ -32,6 +35,10 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--shape", type=int, nargs=3, default=[256, 512, 512], metavar=("NZ", "NY", "NX"))
     ap.add_argument("--host", action="store_true", help="views in pinned host memory, result copied back")
+    ap.add_argument("--tiff", metavar="DIR", default=None,
+                    help="read both views of every time point from 16-bit TIFF stacks under DIR/rank<r>/ and write the "
+                         "deconvolved stack there, inside the timed region (files are created before it)")
+    ap.add_argument("--tiff-files", type=int, default=2, help="distinct input pairs per rank (cycled over the time points)")
     args = ap.parse_args()
 
     import torch
@@ -80,9 +87,30 @@ def main():
     if args.host:
         host_pair = (base_a.cpu().pin_memory(), base_b.cpu().pin_memory())
 
+    tiff_dir = None
+    if args.tiff:
+        from microimagelib_amd import api
+        tiff_dir = os.path.join(args.tiff, f"rank{rank}")
+        os.makedirs(tiff_dir, exist_ok=True)
+        for k in range(args.tiff_files):  # setup, not timed: noisy 16-bit stacks like the microscope writes
+            g = torch.Generator(device="cuda").manual_seed(5000 + 97 * rank + k)
+            for name, base in (("SPIMA", base_a), ("SPIMB", base_b)):
+                vol = (base + torch.randn(base.shape, device="cuda", generator=g) * 3.0).clamp_(0, 65535)
+                api.writetifstack(os.path.join(tiff_dir, f"{name}_{k}.tif"), vol.cpu().numpy(), bits=16)
+        tiff_in = torch.empty((2,) + shape, dtype=torch.float32).pin_memory()
+        tiff_out = torch.empty(shape, dtype=torch.float32).pin_memory()
+
     def load_pair(t):
         t0 = time.perf_counter()
         g = torch.Generator(device="cuda").manual_seed(1000 + t)
+        if tiff_dir:
+            k = t % args.tiff_files
+            for i, name in enumerate(("SPIMA", "SPIMB")):  # decode straight into pinned memory, then one DMA each
+                api.readtifstack(os.path.join(tiff_dir, f"{name}_{k}.tif"), out=tiff_in[i].numpy())
+            a, b = tiff_in[0].cuda(non_blocking=True), tiff_in[1].cuda(non_blocking=True)
+            torch.cuda.synchronize()
+            split["load"] += time.perf_counter() - t0
+            return a, b
         if args.host:
             a, b = host_pair[0].cuda(non_blocking=True), host_pair[1].cuda(non_blocking=True)
         else:
@@ -110,7 +138,11 @@ def main():
 
     def sink(t, decon, tmx, rec):
         t0 = time.perf_counter()
-        if args.host:
+        if tiff_dir:
+            tiff_out.copy_(decon, non_blocking=True)
+            torch.cuda.synchronize()
+            api.writetifstack(os.path.join(tiff_dir, f"Decon_{t}.tif"), tiff_out.numpy(), bits=16)
+        elif args.host:
             host_out.copy_(decon, non_blocking=True)
             torch.cuda.synchronize()
         split["store"] += time.perf_counter() - t0
@@ -127,10 +159,20 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    gather_s = [0.0]
+    real_gather = batch.gather_mip_stack
+
+    def timed_gather(*a, **k):
+        tg = time.perf_counter()
+        out = real_gather(*a, **k)
+        gather_s[0] = time.perf_counter() - tg  # includes waiting for the slowest rank
+        return out
+    batch.gather_mip_stack = timed_gather
     t0 = time.perf_counter()
     stack = batch.run_sharded(tps, load_pair, fuse_pair, policy(), reg_fn, pipe.check_fn, (shape[1], shape[2]),
                               sink=sink, device=coll_dev)
     torch.cuda.synchronize()
+    batch.gather_mip_stack = real_gather
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -144,7 +186,10 @@ def main():
             "metric": "spimFusionBatch time points/s, 512x512x256 dual view (BASELINE.json configs[4])",
             "value": round(args.time_points / elapsed, 3), "unit": "time points/s", "n_gpus": world,
             "time_points": args.time_points, "rl_iterations": args.iters, "reg_mode": args.reg_mode,
-            "elapsed_s": round(elapsed, 3), "views": "pinned host memory" if args.host else "resident in HBM",
+            "elapsed_s": round(elapsed, 3),
+            "views": ("16-bit TIFF stacks on disk, read and written inside the timed region" if tiff_dir else
+                      "pinned host memory" if args.host else "resident in HBM"),
+            "rank0_mip_gather_s": round(gather_s[0], 4),
             "rank0_seconds_per_time_point": {k: round(v / max(n_local, 1), 4) for k, v in split.items()},
             "rank0_cost_evaluations_per_time_point": round(float(np.mean(evals)), 1) if evals else 0,
             "mip_stack": list(stack.shape), "mip_checksum": float(stack.double().sum().item()),
