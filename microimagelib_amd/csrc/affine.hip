@@ -4,7 +4,9 @@
 //
 // Semantics restated from the reference CUDA kernels (include/cukernel.cuh:501-556):
 //   t = M*(x,y,z,1) + 0.5 evaluated left to right in float32 (no FMA: this file is
-//   built with -ffp-contract=off), validity window on t, then a linear "texture"
+//   built with -ffp-contract=off -- the oracle's reading of the source, bit-exact against oracle/reg_oracle.py, whose
+//   trilinear arithmetic is pinned to the reference's own itrilerp2 / affinetransformcpu compiled by gcc; an nvcc build
+//   with --fmad=true may contract the coordinate expression), validity window on t, then a linear "texture"
 //   fetch at t with texel centres at +0.5 and neighbour indices clamped to the edge.
 // Interpolation weights are exact float32 (CUDA's texture unit quantises them to 8
 // fractional bits; see DESIGN.md "Registration numerics").
@@ -15,6 +17,8 @@
 // same sums bit for bit with about half the instructions; DESIGN.md section 4 has the measurements (what bounds these
 // kernels is the texture-address path and VALU issue, not HBM) and the three LDS-staged variants that were built,
 // measured slower and dropped.  Every cost kernel ends in corr_publish (corr_finish.h): one launch per evaluation.
+#include <chrono>
+
 #include "corr_finish.h"
 #include "kernels.h"
 
@@ -266,28 +270,48 @@ CorrTail CorrWorkspace::next(size_t nblocks) {
     if (nblocks == 0 || nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: volume exceeds launch limits");
     if (partials.size() < 2 * nblocks + 2 * kCorrCounters) partials.alloc(2 * nblocks + 2 * kCorrCounters);
     ticket += 1.0;
-    return CorrTail{partials.get(), (int)nblocks, counter.get(), host, ticket};
+    const char *f = getenv("MIL_CORR_FENCES");  // read per evaluation: the tests flip it within one process
+    return CorrTail{partials.get(), (int)nblocks, counter.get(), host, ticket, (f && f[0] == '1') ? 1 : 0};
 }
 
-void CorrWorkspace::wait(hipStream_t s) const {
-    // The last workgroup stores the ticket after the sums (release, system scope).  Poll it: a stream synchronisation
-    // costs ~10 us more per evaluation.  Should the ticket not show up in ~50 ms (a failed launch), fall back to the
-    // synchronisation, which reports the error.
+void CorrWorkspace::wait(hipStream_t s) {
+    // The last workgroup stores the ticket after the sums (system scope).  Poll it: a stream synchronisation costs ~10 us
+    // more per evaluation.  Should the ticket not show up within 100 ms of wall clock (a failed launch, a fault), fall
+    // back to the synchronisation, which reports the error; on any failure the completion counters are zeroed and the
+    // ticket advanced, so that stale counts cannot make a later evaluation elect the wrong "last" workgroup.
     volatile const double *flag = host + 2;
     static const bool no_poll = getenv("MIL_CORR_POLL") && getenv("MIL_CORR_POLL")[0] == '0';
+    auto recover = [&]() {
+        (void)hipStreamSynchronize(s);
+        (void)hipMemsetAsync(counter.get(), 0, (kCorrCounters + 1) * sizeof(unsigned), s);
+        (void)hipStreamSynchronize(s);
+        ticket += 1.0;
+    };
     if (no_poll) {
-        MIL_HIP(hipStreamSynchronize(s));
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess || *flag != ticket) {
+            recover();
+            check_hip(e, "hipStreamSynchronize", __FILE__, __LINE__);
+            throw Error(-1, "corr_sums: the cost kernel did not publish its result");
+        }
         return;
     }
-    for (long spin = 0; spin < 20000000L; ++spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
         if (*flag == ticket) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             return;
         }
         __builtin_ia32_pause();
+        if ((spin & 0xfff) == 0xfff &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.1)
+            break;
     }
-    MIL_HIP(hipStreamSynchronize(s));
-    if (*flag != ticket) throw Error(-1, "corr_sums: the cost kernel did not publish its result");
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess && *flag == ticket) return;  // a slow evaluation (a huge volume), not a failed one
+    recover();
+    check_hip(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    throw Error(-1, "corr_sums: the cost kernel did not publish its result");
 }
 
 void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_dims, const Affine12 &m,

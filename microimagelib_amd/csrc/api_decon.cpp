@@ -12,6 +12,7 @@
 #include "cpu_decon.h"
 #include "cpu_fft.h"
 #include "decon.h"
+#include "trace.h"
 
 using namespace mil;
 
@@ -103,6 +104,7 @@ int run_cpu(float *h_decon, const float *h_img1, const float *h_img2, const floa
 }
 
 void upload_volume(float *d_dst, float *d_stage, const float *h_src, const Geometry &g, hipStream_t s) {
+    TraceRange trace("mil::upload_volume");
     if (g.padded) {  // reference src/api_decon.cpp:225-231
         MIL_HIP(hipMemcpyAsync(d_stage, h_src, g.n_im * sizeof(float), hipMemcpyHostToDevice, s));
         k::pad_stack(d_dst, d_stage, g.box, g.im, s);
@@ -112,6 +114,7 @@ void upload_volume(float *d_dst, float *d_stage, const float *h_src, const Geome
 }
 
 void download_volume(float *h_dst, float *d_src, float *d_stage, const Geometry &g, hipStream_t s) {
+    TraceRange trace("mil::download_volume");
     if (g.padded) {  // reference src/api_decon.cpp:237-243
         k::crop_stack(d_stage, d_src, g.im, g.box, s);
         MIL_HIP(hipMemcpyAsync(h_dst, d_stage, g.n_im * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -222,6 +225,7 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         return 1;  // reference src/api_decon.cpp:316-318
     }
     return guarded("decon_singleview", [&]() -> int {
+        TraceRange trace("libapi::decon_singleview");
         const double t_start = now_s();
         const Geometry g = make_geometry(imSize, psfSize);
         if (gpuMemMode == 0)
@@ -285,6 +289,7 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         return -1;  // reference src/api_decon.cpp:685-687
     }
     return guarded("decon_dualview", [&]() -> int {
+        TraceRange trace("libapi::decon_dualview");
         const double t_start = now_s();
         const Geometry g = make_geometry(imSize, psfSize);
         if (gpuMemMode == 0)

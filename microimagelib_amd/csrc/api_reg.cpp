@@ -6,6 +6,7 @@
 
 #include "../../include/libapi.h"
 #include "reg.h"
+#include "trace.h"
 
 using namespace mil;
 
@@ -66,6 +67,7 @@ extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, un
     }
 
     return guarded("reg3d", [&]() -> int {
+        TraceRange trace("libapi::reg3d");
         const auto t0 = std::chrono::steady_clock::now();
         MIL_HIP(hipSetDevice(deviceNum));
         records[8] = free_mb();

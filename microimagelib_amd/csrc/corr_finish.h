@@ -21,6 +21,21 @@ __device__ __forceinline__ double corr_wave_sum(double v) {
 // at ~6 us apiece -- 0.75 ms per evaluation with one per workgroup.  Instead every datum that crosses workgroups is
 // itself stored and loaded at agent scope (sc1: written through to / read from the memory side), and a workgroup waits
 // for its stores to be acknowledged (s_waitcnt vmcnt(0)) before it counts itself done.
+//
+// Why this is sound on gfx950, and what it rests on.  The LLVM AMDGPU back end's memory-model table for gfx942 (which
+// gfx950 shares; AMDGPUUsage, "Memory Model", code sequences for GFX942) implements
+//   * `store atomic monotonic, agent scope, global`   as  `global_store sc1=1`      -- the store bypasses the non-coherent
+//     per-XCD L2 and completes at the memory side;
+//   * `load atomic monotonic, agent scope, global`    as  `global_load sc1=1`       -- served from the memory side, never
+//     from a stale L2 line of this XCD;
+//   * `atomicrmw monotonic, agent scope`              as  `global_atomic sc1=1`     -- executed at the memory side;
+//   * the release half of `fence release, agent`      as  `buffer_wbl2 sc1=1; s_waitcnt vmcnt(0)`: write back dirty L2
+//     lines, then wait until every earlier store has been acknowledged.
+// Our data are never dirty in L2 (every cross-workgroup store is itself sc1), so the write-back has nothing to do and what
+// remains of the release is exactly the `s_waitcnt vmcnt(0)` issued here; the acquire half (`buffer_inv sc1`) would only
+// discard lines that the sc1 loads do not consult.  This is a hardware argument, outside the HIP memory model, so the
+// fenced form is kept selectable: MIL_CORR_FENCES=1 adds `fence release` before a workgroup counts itself done and
+// `fence acquire` before the last one sums (CorrTail::fenced); tests/test_gpu_reg.py demands the same bits from both.
 __device__ __forceinline__ void corr_store_agent(double *p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -105,7 +120,9 @@ __device__ __forceinline__ void corr_publish_as(int b, double a0, double a1, Cor
         corr_store_agent(t.partials + b, a0);
         corr_store_agent(t.partials + t.nblocks + b, a1);
         corr_stores_done();
+        if (t.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         *flag = corr_count(t.counter + grp) == (unsigned)members - 1u;
+        if (t.fenced && *flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (!*flag) return;
@@ -115,7 +132,9 @@ __device__ __forceinline__ void corr_publish_as(int b, double a0, double a1, Cor
         corr_store_agent(gsum + grp, r0);
         corr_store_agent(gsum + kCorrCounters + grp, r1);
         corr_stores_done();
+        if (t.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         *flag = corr_count(t.counter + kCorrCounters) == (unsigned)groups - 1u;
+        if (t.fenced && *flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (!*flag) return;

@@ -17,6 +17,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -641,7 +642,7 @@ namespace {
 //   < 0.08  plain layout + plane reuse           (translations, pure scales, rotations up to ~2 degrees)
 //   < 0.6   row pairs + plane reuse              (the usual registration matrix: a few degrees AND a few per cent)
 //   else    row pairs, both planes gathered      (large rotations)
-int g_forced_kernel = -1;  // test / profiling aid, corr_padded_force_kernel(): 0-2 one voxel per lane, 3-5 two
+std::atomic<int> g_forced_kernel{-1};  // test / profiling aid (process-wide), corr_padded_force_kernel(): 0-2 one voxel per lane, 3-5 two
 
 int pick_layout(const float *m, bool has_pairs) {
     if (!has_pairs) return 0;

@@ -1,4 +1,5 @@
 #include "decon.h"
+#include "trace.h"
 
 #include <cstring>
 #include <mutex>
@@ -161,6 +162,7 @@ DeconEngine::~DeconEngine() {
 void DeconEngine::synchronize() { MIL_HIP(hipStreamSynchronize(stream_)); }
 
 void DeconEngine::gen_otf(float2 *d_otf, const float *d_psf, Dims P, bool flip, bool normalise) {
+    TraceRange trace("mil::gen_otf");
     float scale = 1.0f;
     if (normalise) {
         const double sum = k::reduce_sync(k::kSum, d_psf, (size_t)P.count(), 0.f, red_, stream_);  // :3283
@@ -321,6 +323,7 @@ void DeconEngine::view_update(float *E, const float *M, const float2 *otf, const
 }
 
 void DeconEngine::run_single(float *E, const float *A, const float2 *otf, const float2 *otf_bp, int iters) {
+    TraceRange trace("mil::rl_single_view (enqueue)");
     if (plan_) {
         run_fused(E, &A, &otf, &otf_bp, 1, iters);
         return;
@@ -330,6 +333,7 @@ void DeconEngine::run_single(float *E, const float *A, const float2 *otf, const 
 
 void DeconEngine::run_dual(float *E, const float *A, const float *B, const float2 *otf1, const float2 *otf2,
                            const float2 *otf_bp1, const float2 *otf_bp2, int iters) {
+    TraceRange trace("mil::rl_dual_view (enqueue)");
     if (plan_) {
         const float *M[2] = {A, B};
         const float2 *o[2] = {otf1, otf2}, *ob[2] = {otf_bp1, otf_bp2};

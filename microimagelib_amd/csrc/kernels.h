@@ -86,6 +86,7 @@ struct CorrTail {  // what the last workgroup of a cost kernel needs (corr_finis
     unsigned *counter;  // [kCorrCounters + 1] workgroups finished so far, by group, and groups finished
     double *host;       // pinned {sum s*s, sum s*t, ticket}
     double ticket;
+    int fenced;         // MIL_CORR_FENCES=1: release / acquire fences around the completion counters (diagnostic)
 };
 struct CorrWorkspace {
     DeviceBuffer<double> partials;
@@ -97,7 +98,7 @@ struct CorrWorkspace {
     CorrWorkspace(const CorrWorkspace &) = delete;
     CorrWorkspace &operator=(const CorrWorkspace &) = delete;
     CorrTail next(size_t nblocks);        // sizes the partials, takes a ticket
-    void wait(hipStream_t s) const;       // until the evaluation of the last ticket has published its sums
+    void wait(hipStream_t s);             // until the evaluation of the last ticket has published its sums
 };
 // Enqueue the fused interpolate + correlate + reduce (ONE launch); the result lands in ws.host, ws.wait() returns
 // once it is there (corr_sums_sync does both).

@@ -10,8 +10,10 @@
 //   * x (TIFF fastest axis) is always the lane axis -- the reference's pad / crop /
 //     flip kernels put threadIdx.x on the slowest axis (include/cukernel.cuh:694,735,
 //     750,768) and are fully uncoalesced; these are not.
-// This file is compiled with -ffp-contract=off so every float op rounds exactly like
-// the reference's separate multiply / subtract kernels (bit-exact vs the oracle).
+// This file is compiled with -ffp-contract=off: every float op rounds on its own, which is how the ORACLE reads the
+// reference's C source (bit-exact against oracle/decon_oracle.py, itself pinned to the reference's CPU helpers compiled
+// by gcc: tests/test_oracle_pinned.py).  It is NOT a statement about a CUDA build of the reference: nvcc's default
+// --fmad=true contracts a*b+c inside e.g. multicomplex3Dkernel, a difference far below the 1e-5 tolerance.
 #include "kernels.h"
 
 #include <cstdint>
@@ -352,22 +354,38 @@ __global__ void rot_y90_kernel(float *__restrict__ out, const float *__restrict_
         in[(size_t)i + (size_t)g.sx * ((size_t)oy + (size_t)g.sy * k)];
 }
 
-// maxprojectionkernel :396-418 -- accumulator starts at 0 (negative data projects to 0).
+// maxprojectionkernel :396-418 -- accumulator starts at 0 (negative data projects to 0).  Whatever the direction, the
+// lanes of a wave read consecutive x (the reference -- and round 1 here -- put the lane index on the z or y stride for the
+// projections along y and x: 122 us for one 512 x 512 x 256 projection where a coalesced pass takes ~50).
+//   dir 1  along z: image [sy][sx]          thread = (x, y), loop over z
+//   dir 2  along y: image [sx][sz] (w = sz) thread = (x, z), loop over y; the (small) output is written strided
+//   dir 3  along x: image [sz][sy] (w = sy) one wave per volume row, lanes stride x, wave-level maximum
+// max is exact and order-independent on the data these see (no NaN), so the tree of dir 3 returns the reference's value.
 __global__ void max_projection_kernel(float *__restrict__ out, const float *__restrict__ in, int sx, int sy, int sz,
-                                      int psx, int psy, int psz, int dir) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int j = blockIdx.y;
-    if (i >= psx || j >= psy) return;
+                                      int dir) {
     const size_t zs = (size_t)sx * sy;
-    float a = 0.0f;
-    if (dir == 1) {
-        for (int k = 0; k < psz; ++k) { float v = in[i + (size_t)sx * j + zs * k]; a = (a > v) ? a : v; }
-    } else if (dir == 2) {
-        for (int k = 0; k < psz; ++k) { float v = in[j + (size_t)sx * k + zs * i]; a = (a > v) ? a : v; }
-    } else {
-        for (int k = 0; k < psz; ++k) { float v = in[k + (size_t)sx * i + zs * j]; a = (a > v) ? a : v; }
+    if (dir == 3) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + wave;  // row = y + sy * z
+        if (row >= (long long)sy * sz) return;
+        const float *p = in + (size_t)row * sx;
+        float a = 0.0f;
+        for (int x = lane; x < sx; x += 64) { const float v = p[x]; a = (a > v) ? a : v; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const float v = __shfl_down(a, off, 64); a = (a > v) ? a : v; }
+        if (lane == 0) out[row] = a;
+        return;
     }
-    out[i + (size_t)j * psx] = a;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (x >= sx) return;
+    float a = 0.0f;
+    if (dir == 1) {  // j = y
+        for (int k = 0; k < sz; ++k) { const float v = in[x + (size_t)sx * j + zs * k]; a = (a > v) ? a : v; }
+        out[x + (size_t)j * sx] = a;
+    } else {         // dir 2: j = z, out[z + x * sz]
+        for (int k = 0; k < sy; ++k) { const float v = in[x + (size_t)sx * k + zs * j]; a = (a > v) ? a : v; }
+        out[j + (size_t)x * sz] = a;
+    }
 }
 
 // circshiftgpukernel / imshiftgpukernel, reference include/cukernel.cuh:457-489: out[p] = in[p - d], circular
@@ -589,14 +607,17 @@ void rot_y90(float *out, const float *in, Dims in_dims, int direction, hipStream
 }
 
 void max_projection(float *out, const float *in, Dims d, int direction, hipStream_t s) {
-    int sx = (int)d.nx, sy = (int)d.ny, sz = (int)d.nz, psx, psy, psz;
-    if (direction == 1) { psx = sx; psy = sy; psz = sz; }       // reference src/api_subfunc.cu:492-501
-    else if (direction == 2) { psx = sz; psy = sx; psz = sy; }
-    else if (direction == 3) { psx = sy; psy = sz; psz = sx; }
-    else throw Error(-1, "max_projection: direction must be 1, 2 or 3");
-    int bx = psx >= 256 ? 256 : 64;
-    hipLaunchKernelGGL(max_projection_kernel, dim3((psx + bx - 1) / bx, psy, 1), dim3(bx), 0, s, out, in, sx, sy, sz,
-                       psx, psy, psz, direction);
+    // image extents per direction: reference src/api_subfunc.cu:492-501 (1: sx x sy, 2: sz x sx, 3: sy x sz)
+    const int sx = (int)d.nx, sy = (int)d.ny, sz = (int)d.nz;
+    if (direction < 1 || direction > 3) throw Error(-1, "max_projection: direction must be 1, 2 or 3");
+    if (direction == 3) {
+        const long long rows = (long long)sy * sz;
+        hipLaunchKernelGGL(max_projection_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, out, in, sx, sy, sz, 3);
+    } else {
+        const int bx = sx >= 256 ? 256 : 64;
+        hipLaunchKernelGGL(max_projection_kernel, dim3((sx + bx - 1) / bx, direction == 1 ? sy : sz, 1), dim3(bx), 0, s, out,
+                           in, sx, sy, sz, direction);
+    }
     MIL_HIP(hipGetLastError());
 }
 

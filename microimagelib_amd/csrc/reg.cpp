@@ -1,4 +1,5 @@
 #include "reg.h"
+#include "trace.h"
 
 #include <chrono>
 #include <cmath>
@@ -386,6 +387,7 @@ void phasor_shift(long long shift[3], const float *d_img1, const float *d_img2, 
 int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, Dims dims,
                         int aff_method, bool flag_tmx, float ftol, int it_limit, bool verbose, float *records,
                         hipStream_t stream, const RegOptions &opt) {
+    TraceRange trace("mil::reg3d_affine");
     const auto t_start = std::chrono::steady_clock::now();
     const size_t n = (size_t)dims.count();
     k::Affine12 aff;  // the reference's global affCoef: matrix of the most recent cost evaluation
@@ -497,12 +499,14 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
     auto stage9 = [&](int n_dof, float tol) {
         dof9 = true;
         dof_num = n_dof;
+        TraceRange stage("mil::powell (<= 9 DOF stage)");
         r = powell_minimize(p9, xi9, 9, n_dof, tol, cost, &evals, it_limit);
         if (opt.matrix_from_optimum) dof9tomatrix(aff.m, p9, n_dof);
     };
     auto stage12 = [&](float tol) {
         dof9 = false;
         dof_num = 12;
+        TraceRange stage("mil::powell (12 DOF stage)");
         r = powell_minimize(p12, xi12, 12, 12, tol, cost, &evals, it_limit);
         if (opt.matrix_from_optimum) p2matrix(aff.m, p12);
     };

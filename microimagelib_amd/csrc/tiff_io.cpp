@@ -21,6 +21,7 @@ namespace {
 struct Slice {
     uint32_t width = 0, height = 0;
     uint16_t bits = 0, compression = 1, sample_format = 1, samples = 1;
+    bool has_sample_format = false;
     std::vector<uint64_t> strip_offsets, strip_bytes;
 };
 
@@ -34,12 +35,27 @@ public:
         else if (h[0] == 'M' && h[1] == 'M') big_endian_ = true;
         else fail("not a TIFF file");
         if (u16(h + 2) != 42) fail("unsupported TIFF flavour (only classic TIFF, magic 42)");
+        if (fseeko(f_, 0, SEEK_END) != 0) fail("seek failed");
+        file_size_ = (uint64_t)ftello(f_);
         uint64_t ifd = u32(h + 4);
         while (ifd != 0) {
             slices_.push_back(read_ifd(ifd, &ifd));
             if (slices_.size() > (1u << 24)) fail("IFD chain too long");
         }
         if (slices_.empty()) fail("no image directories");
+        // The callers size their buffers from slice 0 (gettifinfo): every directory must describe the same kind of
+        // slice -- a thumbnail / pyramid level, a slice of another depth or a corrupt directory would otherwise be
+        // written past the end of the caller's buffer.
+        const Slice &s0 = slices_[0];
+        if (s0.width == 0 || s0.height == 0) fail("empty slice");
+        if (s0.samples != 1) fail("only 1 sample per pixel is supported");
+        if (s0.compression != 1) fail("compressed TIFF is not supported");
+        if (s0.bits == 32 && s0.has_sample_format && s0.sample_format != 3)
+            fail("32-bit integer samples are not supported (expected IEEE float)");
+        for (const Slice &s : slices_)
+            if (s.width != s0.width || s.height != s0.height || s.bits != s0.bits || s.samples != s0.samples ||
+                s.compression != s0.compression || s.sample_format != s0.sample_format)
+                fail("slices differ in size, depth or sample format (thumbnail / pyramid directories are not supported)");
     }
     ~TiffReader() {
         if (f_) fclose(f_);
@@ -49,9 +65,7 @@ public:
 
     // raw bytes of slice i (all strips concatenated) into dst (width*height*bits/8 bytes)
     void read_slice(size_t i, unsigned char *dst) {
-        const Slice &s = slices_[i];
-        if (s.compression != 1) fail("compressed TIFF is not supported");
-        if (s.samples != 1) fail("only 1 sample per pixel is supported");
+        const Slice &s = slices_[i];  // homogeneous with slice 0, uncompressed, 1 sample: checked at open
         const uint64_t want = (uint64_t)s.width * s.height * (s.bits / 8);
         uint64_t got = 0;
         for (size_t k = 0; k < s.strip_offsets.size() && got < want; ++k) {
@@ -84,6 +98,7 @@ private:
         const size_t sz = (type == 3) ? 2 : (type == 4) ? 4 : (type == 1 || type == 2) ? 1 : 0;
         std::vector<uint64_t> out;
         if (sz == 0 || count == 0) return out;
+        if ((uint64_t)count * sz > file_size_) fail("tag data larger than the file");
         std::vector<unsigned char> buf((size_t)count * sz);
         if ((size_t)count * sz <= 4) {
             memcpy(buf.data(), entry + 8, buf.size());
@@ -123,7 +138,7 @@ private:
             case 273: s.strip_offsets = v; break;
             case 277: s.samples = (uint16_t)v[0]; break;
             case 279: s.strip_bytes = v; break;
-            case 339: s.sample_format = (uint16_t)v[0]; break;
+            case 339: s.sample_format = (uint16_t)v[0]; s.has_sample_format = true; break;
             }
         }
         *next = u32(ent.data() + (size_t)n * 12);
@@ -133,6 +148,7 @@ private:
     FILE *f_;
     std::string path_;
     bool big_endian_ = false;
+    uint64_t file_size_ = 0;
     std::vector<Slice> slices_;
 };
 
@@ -147,18 +163,23 @@ void swap_bytes(unsigned char *p, size_t count, size_t width) {
 
 class TiffWriter {
 public:
-    explicit TiffWriter(const char *path) : f_(fopen(path, "wb")) {
+    explicit TiffWriter(const char *path) : f_(fopen(path, "wb")), path_(path) {
         if (!f_) {
             fprintf(stderr, "*** Failed to create file!!! Please check the directory: %s\n", path);
             exit(1);  // reference src/apifunc.cpp:248-251
         }
         const unsigned char hdr[8] = {'I', 'I', 42, 0, 0, 0, 0, 0};
-        fwrite(hdr, 1, 8, f_);
+        put(hdr, 8);
         link_pos_ = 4;
         pos_ = 8;
     }
-    ~TiffWriter() {
-        if (f_) fclose(f_);
+    ~TiffWriter() { close(); }
+    // flushes and closes; a short write (full disk) is an error, not a silently truncated stack
+    void close() {
+        if (!f_) return;
+        FILE *f = f_;
+        f_ = nullptr;
+        if (fclose(f) != 0) fail();
     }
     void add_slice(const void *data, uint32_t width, uint32_t height, uint16_t bits, bool ieee_float) {
         const uint64_t nbytes = (uint64_t)width * height * (bits / 8);
@@ -167,10 +188,11 @@ public:
             exit(1);
         }
         const uint32_t data_off = (uint32_t)pos_;
-        fwrite(data, 1, nbytes, f_);
+        put(data, nbytes);
         pos_ += nbytes;
         if (pos_ & 1) {
-            fputc(0, f_);
+            const unsigned char zero = 0;
+            put(&zero, 1);
             ++pos_;
         }
         struct Entry { uint16_t tag, type; uint32_t count, value; };
@@ -194,25 +216,33 @@ public:
     }
 
 private:
+    [[noreturn]] void fail() const {
+        fprintf(stderr, "*** TIFF write error (disk full or I/O error): %s\n", path_.c_str());
+        exit(1);
+    }
+    void put(const void *data, size_t n) {
+        if (fwrite(data, 1, n, f_) != n) fail();
+    }
     void put16(uint16_t v) {
         unsigned char b[2] = {(unsigned char)(v & 255), (unsigned char)(v >> 8)};
-        fwrite(b, 1, 2, f_);
+        put(b, 2);
         pos_ += 2;
     }
     void put32(uint32_t v) {
         unsigned char b[4] = {(unsigned char)(v & 255), (unsigned char)((v >> 8) & 255),
                               (unsigned char)((v >> 16) & 255), (unsigned char)(v >> 24)};
-        fwrite(b, 1, 4, f_);
+        put(b, 4);
         pos_ += 4;
     }
     void patch32(uint64_t where, uint32_t v) {
-        fseeko(f_, (off_t)where, SEEK_SET);
+        if (fseeko(f_, (off_t)where, SEEK_SET) != 0) fail();
         unsigned char b[4] = {(unsigned char)(v & 255), (unsigned char)((v >> 8) & 255),
                               (unsigned char)((v >> 16) & 255), (unsigned char)(v >> 24)};
-        fwrite(b, 1, 4, f_);
-        fseeko(f_, (off_t)pos_, SEEK_SET);
+        put(b, 4);
+        if (fseeko(f_, (off_t)pos_, SEEK_SET) != 0) fail();
     }
     FILE *f_;
+    std::string path_;
     uint64_t pos_ = 0, link_pos_ = 0;
 };
 
@@ -327,6 +357,7 @@ extern "C" void writetifstack(char *tifdir, float *h_Image, unsigned int *imsize
     } else {
         printf("Image bit per sample is not supported, please set bitPerPample to 16 or 32 !!!\n\n");
     }
+    w.close();
 }
 
 extern "C" void writetifstack_16to16(char *tifdir, unsigned short *h_Image, unsigned int *imsize) {
@@ -334,4 +365,5 @@ extern "C" void writetifstack_16to16(char *tifdir, unsigned short *h_Image, unsi
     TiffWriter w(tifdir);
     for (unsigned int n = 0; n < imsize[2]; ++n)
         w.add_slice(h_Image + (size_t)n * plane, imsize[0], imsize[1], 16, false);
+    w.close();
 }

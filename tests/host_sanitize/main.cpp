@@ -12,6 +12,16 @@
 #include "../../microimagelib_amd/csrc/powell.h"
 
 int main(int argc, char **argv) {
+    if (argc > 3 && std::string(argv[2]) == "read") {
+        // malformed-input mode: size the buffer from gettifinfo like every caller does, then read.  The library must
+        // refuse the file (exit 1 with a TIFF read error) -- never write past the buffer (ASan would report it).
+        unsigned sz[3] = {0, 0, 0};
+        gettifinfo(argv[3], sz);
+        std::vector<float> buf((size_t)sz[0] * sz[1] * sz[2]);
+        readtifstack(buf.data(), argv[3], sz);
+        printf("read %u x %u x %u\n", sz[0], sz[1], sz[2]);
+        return 0;
+    }
     const std::string path = std::string(argc > 1 ? argv[1] : "/tmp") + "/sanitize_roundtrip.tif";
     const unsigned sizes[][3] = {{7, 5, 3}, {1, 1, 1}, {33, 2, 1}, {16, 16, 9}};
     for (auto &sz : sizes) {

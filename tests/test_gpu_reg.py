@@ -390,6 +390,37 @@ def test_full_size_registration_properties(dev):
     assert np.allclose(tmx, ident, atol=0.05)
 
 
+def test_fenced_and_fence_free_tails_agree(dev, monkeypatch):
+    """The cost kernels hand their partial sums from workgroup to workgroup with agent-scope (sc1) stores / loads and
+    `s_waitcnt vmcnt(0)` instead of release / acquire fences (csrc/corr_finish.h).  MIL_CORR_FENCES=1 adds the fences:
+    both forms must publish the same bits, for every kernel, evaluation after evaluation."""
+    import torch
+    shape = (128, 256, 256)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    vol = torch.rand(shape, device="cuda", generator=g) * 300 - 100
+    tgt = torch.rand(shape, device="cuda", generator=g) * 300 - 100
+    pad = dev.PaddedSource(vol)
+    ident = np.eye(3, 4, dtype=np.float32).reshape(12)
+    rot = ident.copy()
+    c, s_ = np.cos(np.deg2rad(4.0)), np.sin(np.deg2rad(4.0))
+    rot[[0, 2, 8, 10]] = np.array([c, -s_, s_, c], dtype=np.float32) * np.float32(0.98)
+    rot[[3, 7, 11]] = (3.0, -2.0, 6.0)
+    for kern in (-1, 0, 1, 2, 3, 4, 5):
+        dev.corr_padded_force_kernel(kern)
+        for m in (ident, rot):
+            monkeypatch.delenv("MIL_CORR_FENCES", raising=False)
+            free = [dev.corr_sums(tgt, pad, m) for _ in range(3)]
+            monkeypatch.setenv("MIL_CORR_FENCES", "1")
+            fenced = [dev.corr_sums(tgt, pad, m) for _ in range(3)]
+            assert len(set(free + fenced)) == 1, (kern, free, fenced)
+    dev.corr_padded_force_kernel(-1)
+    monkeypatch.setenv("MIL_CORR_FENCES", "1")
+    a = dev.corr_sums(tgt, vol, rot)  # the general kernel (csrc/affine.hip) shares the tail
+    monkeypatch.delenv("MIL_CORR_FENCES")
+    assert dev.corr_sums(tgt, vol, rot) == a == dev.corr_sums(tgt, pad, rot)
+    pad.close()
+
+
 def test_cost_tail_sums_many_workgroups(dev):
     """196 608 workgroups (> 2048 partials per group of the two-level tail, csrc/corr_finish.h) on a 4096 x 4096 x 48
     volume, which is also beyond the padded kernels' 32-bit offsets: a constant volume under the identity has sums that

@@ -23,3 +23,43 @@ def test_tiff_and_powell_clean_under_asan_ubsan(tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
     assert "powell:" in run.stdout
+
+    # malformed stacks: a second directory that is larger / deeper than the first, and a tag whose count exceeds the file
+    import struct
+
+    def tiff(slices, bogus_count=False):
+        """Little-endian classic TIFF, one strip per slice; slices = [(width, height, bits)]."""
+        blob = bytearray(b"II*\x00\x00\x00\x00\x00")
+        link = 4
+        for (w, h, bits) in slices:
+            data_off = len(blob)
+            blob += bytes(w * h * bits // 8)
+            if len(blob) & 1:
+                blob += b"\x00"
+            ifd = len(blob)
+            blob[link:link + 4] = struct.pack("<I", ifd)
+            ents = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, bits), (259, 3, 1, 1), (273, 4, 1, data_off),
+                    (277, 3, 1, 1), (279, 4, 0x7FFFFFFF if bogus_count else 1, w * h * bits // 8)]
+            if bits == 32:
+                ents.append((339, 3, 1, 3))
+            blob += struct.pack("<H", len(ents))
+            for e in ents:
+                blob += struct.pack("<HHII", *e)
+            link = len(blob)
+            blob += b"\x00\x00\x00\x00"
+        return bytes(blob)
+
+    cases = {"bigger_second_slice.tif": tiff([(4, 4, 16), (64, 64, 16)]),
+             "deeper_second_slice.tif": tiff([(8, 8, 16), (8, 8, 32)]),
+             "huge_tag_count.tif": tiff([(8, 8, 16)], bogus_count=True)}
+    for name, blob in cases.items():
+        path = tmp_path / name
+        path.write_bytes(blob)
+        bad = subprocess.run([str(exe), str(tmp_path), "read", str(path)], capture_output=True, text=True,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0"))
+        assert bad.returncode == 1, (name, bad.returncode, bad.stderr[-1500:])
+        assert "TIFF read error" in bad.stderr and "AddressSanitizer" not in bad.stderr, (name, bad.stderr[-1500:])
+    good = tmp_path / "good.tif"
+    good.write_bytes(tiff([(8, 8, 16), (8, 8, 16)]))
+    ok = subprocess.run([str(exe), str(tmp_path), "read", str(good)], capture_output=True, text=True)
+    assert ok.returncode == 0 and "read 8 x 8 x 2" in ok.stdout, ok.stderr[-1500:]
