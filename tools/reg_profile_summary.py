@@ -9,7 +9,7 @@ NAMES = ["identity", "rot3_scale1.02", "rot10", "rot45"]  # order and 51 launche
 
 
 def is_cost(name):
-    return any(k in name for k in ("corr_kernel", "corr_padded_kernel", "corr_rowpair_kernel"))
+    return "corr_" in name and "kernel" in name  # corr_kernel, corr_padded_kernel, corr_rowpair_kernel, corr_pair_kernel
 
 
 def newest(pattern):
