@@ -16,7 +16,7 @@ cat $out/tests.log $out/bench.json
 # BASELINE.json configs[4] on one GPU: every time point registered / views from pinned host memory / one shared matrix
 ( timeout 300 python tools/bench_batch.py --time-points 8; timeout 300 python tools/bench_batch.py --time-points 8 --host; timeout 300 python tools/bench_batch.py --time-points 8 --reg-mode 1 ) > $out/bench_batch.json 2> $out/bench_batch.err
 # the command-line tool end to end on TIFF files: our main against the reference's main, same library
-( timeout 600 python tools/bench_cli_batch.py --time-points 6 --reg-mode 2; timeout 600 python tools/bench_cli_batch.py --time-points 4 --reg-mode 3 ) > $out/bench_cli_batch.json 2> $out/bench_cli_batch.err
+( timeout 600 python tools/bench_cli_batch.py --time-points 12 --reg-mode 2; timeout 600 python tools/bench_cli_batch.py --time-points 4 --reg-mode 3 ) > $out/bench_cli_batch.json 2> $out/bench_cli_batch.err
 # registration cost kernel (tools/reg_profile_summary.py condenses these)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/reg_stats -- python tools/bench_corr.py > $out/reg_stats.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/reg_pmc1 -- python tools/bench_corr.py > $out/reg_pmc1.log 2>&1
