@@ -25,6 +25,11 @@ const char *mil_version(void);
 int mil_device_count(void);
 int mil_set_device(int device);               /* cudaSetDevice(deviceNum), src/api_decon.cpp:102 */
 int mil_snap_transform_size(int n);
+/* Interpolation weights of every resample / cost kernel: 0 = exact float32 (default), 8 = rounded to 8 fractional bits,
+ * emulating the CUDA texture unit the reference samples through (include/cukernel.cuh:510-522, 545-546; rounding to nearest
+ * is an assumption, the CUDA guide documents only the format).  A comparison aid for data produced by the CUDA build;
+ * process-wide; any other value returns control to MIL_TEX_WEIGHT_BITS.  Returns the setting in force. */
+int mil_set_texture_weight_bits(int bits);
 /* Device buffers freed inside the library are kept for the next call of the same size (the reference re-allocates ~2 GB per
  * libapi.h call); this returns them to the driver.  Returns the number of bytes released.  MIL_POOL_MB caps the cache. */
 size_t mil_release_cached_memory(void);           /* snapTransformSize, src/api_subfunc.cu:57-87 */

@@ -17,6 +17,7 @@
 // same sums bit for bit with about half the instructions; DESIGN.md section 4 has the measurements (what bounds these
 // kernels is the texture-address path and VALU issue, not HBM) and the three LDS-staged variants that were built,
 // measured slower and dropped.  Every cost kernel ends in corr_publish (corr_finish.h): one launch per evaluation.
+#include <atomic>
 #include <chrono>
 
 #include "corr_finish.h"
@@ -39,6 +40,7 @@ struct AffineArgs {
     float m[12];
     int tx, ty, tz;  // target / output dims
     int sx, sy, sz;  // source dims
+    float wq;        // 0: exact float32 weights; 256: weights rounded to 8 fractional bits (texture_weight_bits)
 };
 
 __device__ __forceinline__ float coord(const float *r, float ix, float iy, float iz) {
@@ -53,11 +55,16 @@ struct Tap {
     float w0, w1;
 };
 
-__device__ __forceinline__ Tap make_tap(float t, int n) {
+// wq > 0: CUDA-texture emulation.  The CUDA programming guide (texture fetching, linear filtering) stores the weight
+// "in 9-bit fixed point format with 8 bits of fractional value (so 1.0 is exactly represented)"; it does not say how it
+// rounds -- round to nearest is ASSUMED here -- nor how the filter arithmetic is carried out (ours stays
+// w0*q0 + w1*q1 in float32, x then y then z).  A comparison aid for volumes produced by the CUDA build, off by default.
+__device__ __forceinline__ Tap make_tap(float t, int n, float wq) {
     float b = t - 0.5f;
     float f = floorf(b);
     Tap p;
     p.w1 = b - f;
+    if (wq > 0.0f) p.w1 = floorf(p.w1 * wq + 0.5f) / wq;
     p.w0 = 1.0f - p.w1;
     // Only called for t inside the validity window, so i = floor(t - 0.5) lies in [-1, n-1]: the edge clamp of the
     // reference's texture fetch reduces to one max and one min.
@@ -75,8 +82,8 @@ struct __attribute__((packed, aligned(4))) Pair {
 };
 
 __device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int sx, int sy, int sz, float tx, float ty,
-                                              float tz) {
-    Tap X = make_tap(tx, sx), Y = make_tap(ty, sy), Z = make_tap(tz, sz);
+                                              float tz, float wq) {
+    Tap X = make_tap(tx, sx, wq), Y = make_tap(ty, sy, wq), Z = make_tap(tz, sz, wq);
     const size_t row = (size_t)sx, plane = (size_t)sx * sy;
     const float *p00 = src + Z.i0 * plane + Y.i0 * row;
     const float *p01 = src + Z.i0 * plane + Y.i1 * row;
@@ -114,8 +121,8 @@ struct PlaneCache {
 };
 
 __device__ __forceinline__ float fetch_linear_cached(const float *__restrict__ src, int sx, int sy, int sz, float tx,
-                                                     float ty, float tz, PlaneCache &pc) {
-    Tap X = make_tap(tx, sx), Y = make_tap(ty, sy), Z = make_tap(tz, sz);
+                                                     float ty, float tz, PlaneCache &pc, float wq) {
+    Tap X = make_tap(tx, sx, wq), Y = make_tap(ty, sy, wq), Z = make_tap(tz, sz, wq);
     const size_t row = (size_t)sx, plane = (size_t)sx * sy;
     const int b = X.i0 < sx - 2 ? X.i0 : sx - 2;  // sx >= 2 guaranteed by the launcher
     const bool lo0 = X.i0 == b, lo1 = X.i1 == b;
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restri
     float v = 0.0f;
     const bool lower = STRICT ? (tx > 0 && ty > 0 && tz > 0) : (tx >= 0 && ty >= 0 && tz >= 0);
     if (lower && tx < (float)a.sx && ty < (float)a.sy && tz < (float)a.sz)
-        v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
+        v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
     out[(size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z)] = v;
 }
 
@@ -198,8 +205,8 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
             const float tz = coord(a.m + 8, ix, iy, iz);
             float sv = 0.0f;
             if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
-                sv = CACHE ? fetch_linear_cached(src, a.sx, a.sy, a.sz, tx, ty, tz, pc)
-                           : fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz);
+                sv = CACHE ? fetch_linear_cached(src, a.sx, a.sy, a.sz, tx, ty, tz, pc, a.wq)
+                           : fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
             const float tv = *tp;
             if (FLOAT_PRODUCTS) {
                 const float q = sv * sv, c = tv * sv;
@@ -240,10 +247,23 @@ AffineArgs make_args(Dims t, Dims s, const Affine12 &m) {
     for (int i = 0; i < 12; ++i) a.m[i] = m.m[i];
     a.tx = (int)t.nx; a.ty = (int)t.ny; a.tz = (int)t.nz;
     a.sx = (int)s.nx; a.sy = (int)s.ny; a.sz = (int)s.nz;
+    a.wq = texture_weight_bits() == 8 ? 256.0f : 0.0f;
     return a;
 }
 
+std::atomic<int> g_weight_bits{-1};  // -1: not set through the API, MIL_TEX_WEIGHT_BITS decides
+
 }  // namespace
+
+// 0 (default): exact float32 interpolation weights; 8: weights rounded to 8 fractional bits like the CUDA texture unit
+// the reference samples through (include/cukernel.cuh:510-522, 545-546) -- see make_tap.  Process-wide.
+int texture_weight_bits() {
+    const int v = g_weight_bits.load();
+    if (v >= 0) return v;
+    const char *e = getenv("MIL_TEX_WEIGHT_BITS");
+    return (e && atoi(e) == 8) ? 8 : 0;
+}
+void set_texture_weight_bits(int bits) { g_weight_bits.store(bits == 8 ? 8 : bits == 0 ? 0 : -1); }
 
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s,
                      bool strict_window) {

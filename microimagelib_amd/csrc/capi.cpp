@@ -80,6 +80,11 @@ int mil_set_device(int device) {
 
 int mil_snap_transform_size(int n) { return snap_transform_size(n); }
 
+int mil_set_texture_weight_bits(int bits) {
+    k::set_texture_weight_bits(bits);
+    return k::texture_weight_bits();
+}
+
 size_t mil_release_cached_memory(void) {
     decon_cache_drop();
     return pool_release_all();

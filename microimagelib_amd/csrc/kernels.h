@@ -75,6 +75,11 @@ double reduce_dot_sync(const float *a, const float *b, size_t n, float ca, float
 struct Affine12 {
     float m[12];
 };
+// Interpolation weights: 0 = exact float32 (default), 8 = rounded to 8 fractional bits (CUDA texture-unit emulation,
+// a comparison aid: affine.hip make_tap).  Process-wide; MIL_TEX_WEIGHT_BITS=8 sets it from the environment.  With 8 the
+// registration evaluates its cost with the general kernel (the padded-source kernels implement exact weights only).
+int texture_weight_bits();
+void set_texture_weight_bits(int bits);  // 0 | 8 | anything else: back to the environment's choice
 // out[x,y,z] = trilinear(src, M*(x,y,z,1)) inside the window, 0 outside.
 // strict_window: lower bound 0 < t instead of 0 <= t (the reference's 2-D transform kernel).
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m,

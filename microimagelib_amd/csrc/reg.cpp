@@ -446,7 +446,8 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
     // The cost kernel reads the source through a copy with a replicated one-voxel border (corr_padded.hip); volumes
     // beyond its 32-bit offset range keep the general kernel.  Same sums either way.
     k::PaddedSource src_pad;
-    const bool padded = k::PaddedSource::eligible(dims, dims) && !(getenv("MIL_CORR_UNPADDED") && getenv("MIL_CORR_UNPADDED")[0] == '1');
+    const bool padded = k::PaddedSource::eligible(dims, dims) && k::texture_weight_bits() == 0 &&
+                        !(getenv("MIL_CORR_UNPADDED") && getenv("MIL_CORR_UNPADDED")[0] == '1');
     if (padded) {
         src_pad.build(src_ms.get(), dims, stream);
         src_ms.release();

@@ -142,6 +142,12 @@ class PaddedSource:
             pass
 
 
+def set_texture_weight_bits(bits: int = 0) -> int:
+    """0: exact float32 interpolation weights (default); 8: weights rounded to 8 fractional bits (CUDA texture-unit
+    emulation, comparison aid).  Process-wide; returns the setting in force."""
+    return int(_lib.load().mil_set_texture_weight_bits(int(bits)))
+
+
 def corr_padded_force_kernel(kernel: int = -1):
     """Test / profiling aid: pin the padded-source cost kernel (0 plain + plane reuse, 1 row pairs, 2 row pairs + plane
     reuse, 3-5 the same with two voxels per lane); -1 restores the per-matrix choice."""

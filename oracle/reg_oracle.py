@@ -169,6 +169,9 @@ def _coords(m, shape, z_range=None):
     return out  # tx, ty, tz
 
 
+WEIGHT_BITS = 0  # 8: emulate the CUDA texture unit's 8 fractional weight bits (round to nearest assumed); test aid
+
+
 def _trilinear(src, tx, ty, tz):
     """Linear texture fetch with unnormalised coordinates, texel centres at +0.5,
     neighbour indices clamped to the edge (BindTexture, src/api_subfunc.cu:885-895;
@@ -182,6 +185,8 @@ def _trilinear(src, tx, ty, tz):
         b = t - half
         i0f = np.floor(b)
         w1 = (b - i0f).astype(f32)
+        if WEIGHT_BITS == 8:  # CUDA guide: 9-bit fixed point with 8 bits of fractional value, 1.0 exactly represented
+            w1 = (np.floor(w1 * f32(256) + f32(0.5)) / f32(256)).astype(f32)
         w0 = (one - w1).astype(f32)
         i0 = i0f.astype(np.int64)
         i1 = i0 + 1

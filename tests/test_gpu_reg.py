@@ -390,6 +390,43 @@ def test_full_size_registration_properties(dev):
     assert np.allclose(tmx, ident, atol=0.05)
 
 
+def test_texture_weight_emulation_switch(dev, api):
+    """mil_set_texture_weight_bits(8) / MIL_TEX_WEIGHT_BITS=8: interpolation weights rounded to 8 fractional bits like
+    the CUDA texture unit the reference samples through (include/cukernel.cuh:510-522, 545-546).
+    Resample and cost sums equal the oracle's with the same quantisation, differ from the exact-weight results by
+    what 1/512 of a voxel can do, and the switch restores the default bits."""
+    rng = np.random.default_rng(21)
+    src = rng.uniform(0, 500, (20, 34, 70)).astype(f32)
+    tgt = rng.uniform(0, 500, (18, 30, 64)).astype(f32)
+    m = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=f32) + rng.normal(0, 0.03, 12).astype(f32)
+    m[[3, 7, 11]] = (1.37, -0.61, 2.22)
+    ds, dt = T(src), T(tgt)
+    exact = dev.affine_resample(ds, m, tgt.shape).cpu().numpy()
+    exact_sums = dev.corr_sums(dt, ds, m)
+    assert dev.set_texture_weight_bits(8) == 8
+    try:
+        ro.WEIGHT_BITS = 8
+        got = dev.affine_resample(ds, m, tgt.shape).cpu().numpy()
+        want = ro.affine_transform(src, m, tgt.shape)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        ss, st = dev.corr_sums(dt, ds, m)
+        wss, wst = ro.corr_sums(tgt, src, m)
+        assert abs(ss - wss) <= 1e-12 * wss and abs(st - wst) <= 1e-11 * wss
+        diff = np.abs(got - exact)
+        assert 0 < diff.max() < 500 * 3 / 512 + 1e-3  # three axes, each weight off by at most 1/512
+        # the registration falls back to the general cost kernel and still converges on a self-registration
+        vol = T(do.blob_volume((32, 48, 64), n_blobs=10, seed=4))
+        _, tmx, rec = dev.reg3d_affine(vol, vol, aff_method=1, it_limit=40)
+        assert rec[1] > 0.999999 and np.allclose(tmx, np.eye(3, 4, dtype=f32).reshape(12), atol=0.05)
+        out = api.atrans3dgpu(src, m, tgt.shape)  # the libapi.h entry points follow the same switch
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    finally:
+        ro.WEIGHT_BITS = 0
+        assert dev.set_texture_weight_bits(0) == 0
+    again = dev.affine_resample(ds, m, tgt.shape).cpu().numpy()
+    assert np.array_equal(again.view(np.uint32), exact.view(np.uint32)) and dev.corr_sums(dt, ds, m) == exact_sums
+
+
 def test_fenced_and_fence_free_tails_agree(dev, monkeypatch):
     """The cost kernels hand their partial sums from workgroup to workgroup with agent-scope (sc1) stores / loads and
     `s_waitcnt vmcnt(0)` instead of release / acquire fences (csrc/corr_finish.h).  MIL_CORR_FENCES=1 adds the fences:
