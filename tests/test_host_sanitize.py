@@ -63,3 +63,26 @@ def test_tiff_and_powell_clean_under_asan_ubsan(tmp_path):
     good.write_bytes(tiff([(8, 8, 16), (8, 8, 16)]))
     ok = subprocess.run([str(exe), str(tmp_path), "read", str(good)], capture_output=True, text=True)
     assert ok.returncode == 0 and "read 8 x 8 x 2" in ok.stdout, ok.stderr[-1500:]
+
+
+@pytest.mark.timeout(600)
+def test_cpu_decon_path_clean_under_asan_ubsan(tmp_path):
+    """The gpuMemMode 0 host path (bundled FFT + RL loop, threaded) under ASan + UBSan on ragged / odd-radix boxes."""
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    rocm_inc = "/opt/rocm/include"
+    if not os.path.isdir(rocm_inc):
+        pytest.skip("HIP headers not available (float2 / Dims come from mil_common.h)")
+    exe = tmp_path / "cpu_decon_sanitize"
+    csrc = os.path.join(ROOT, "microimagelib_amd", "csrc")
+    build = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-pthread", "-fsanitize=address,undefined",
+                            "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                            "-D__HIP_PLATFORM_AMD__", "-I" + rocm_inc,
+                            os.path.join(ROOT, "tests", "host_sanitize", "cpu_decon_main.cpp"),
+                            os.path.join(csrc, "cpu_fft.cpp"), os.path.join(csrc, "cpu_decon.cpp"), "-o", str(exe)],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    assert "cpu decon clean" in run.stdout
