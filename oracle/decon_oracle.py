@@ -1,13 +1,16 @@
 """ORACLE (test infrastructure, not product): NumPy restatement of the reference
 Richardson-Lucy deconvolution path, GPU-path semantics (``gpuMemMode 1``).
 
-PARITY STATUS: **unpinned by upstream tests** -- eguomin/microImageLib ships no
-tests / golden vectors for this path, and its sources
-cannot be compiled in this image without stand-ins for CUDA, cuFFT, FFTW and
-libtiff headers, so there is no `oracle/_ref` build of the decon path.  This
-restatement follows the reference source line by line (citations below) and
-is additionally checked against closed-form known answers (tests/test_oracle_decon.py).
-Only the Powell optimiser has a real reference build (oracle/Makefile).
+PARITY STATUS: **partly pinned**.  eguomin/microImageLib ships no tests / golden vectors for
+this path.  What IS pinned, bit for bit, to reference code compiled by gcc
+(oracle/Makefile target `subfunc`: the plain-C++ host helpers of src/api_subfunc.cu, cut out by
+line range; tests/test_oracle_pinned.py): snap_transform_size, flip3, pad_psf (equal-size case),
+pad_stack, crop_stack, align_size, clamp_small, sum_f64, cmul, rl_ratio, rl_update.  What is NOT:
+the order of operations of the RL loop and of gen_otf (restated from decon_*_OTF1 / genOTFgpu
+below; those functions need cuda_runtime.h / cufft.h / fftw3.h and cannot be built here without
+stand-ins, so they are not built) and the FFT itself (pocketfft here; any unnormalised DFT is a
+valid stand-in for cuFFT / FFTW up to rounding).  Additionally checked against closed-form known
+answers (tests/test_oracle.py).
 
 Array convention: every volume is a C-ordered ``[z][y][x]`` float32 ndarray that
 views the TIFF-ordered flat buffer ``idx = x + sx*(y + sy*z)`` the C API takes

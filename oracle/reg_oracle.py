@@ -2,12 +2,18 @@
 3-D affine registration path -- matrix parameterisations, trilinear resample,
 correlation cost and the ``reg3d_affine1`` driver.
 
-PARITY STATUS: kernels **unpinned by upstream** (no tests / vectors in the
-reference; ``reg3d`` has no CPU path: src/api_reg.cpp:390-393) -- the restatement
-follows the CUDA source (citations below) with *exact float32* trilinear weights
-(the CUDA texture unit quantises weights to 8 fractional bits).
-The optimiser itself IS pinned: ``oracle/powell_oracle.py`` is checked bit-for-bit
-against ``oracle/_ref/libpowell_ref.so``, built from the reference's own
+PARITY STATUS: **partly pinned**.  The reference has no tests / vectors for this path and
+``reg3d`` has no CPU path (src/api_reg.cpp:390-393).  Pinned bit for bit to reference code compiled
+by gcc (oracle/Makefile target `subfunc`; tests/test_oracle_pinned.py): p2matrix, matrix2p,
+matrixmultiply, dof9tomatrix, rot2matrix, mean_subtract's arithmetic, and -- through the reference's
+own itrilerp2 / affinetransformcpu / corrfunccpu2 -- the trilinear interpolation (order of the three
+lerps, weight definitions) and the correlation sums wherever the CPU helper's bounds rule and the
+CUDA kernel's window agree.  Restated from the CUDA source without a runnable reference: the
+validity windows, the clamp addressing at the rim, the +0.5 texel-centre convention and the
+``reg3d_affine1`` driver.  Interpolation weights are *exact float32* by default (the CUDA texture
+unit quantises them to 8 fractional bits); ``WEIGHT_BITS = 8`` mirrors the
+product's emulation switch.  The optimiser itself IS pinned: ``oracle/powell_oracle.py`` is checked
+bit-for-bit against ``oracle/_ref/libpowell_ref.so``, built from the reference's own
 ``src/api_powell.c`` (oracle/Makefile).
 
 Registration layout: API names used directly, ``x`` fastest
