@@ -231,6 +231,12 @@ def test_padded_cost_kernel_is_bit_identical(dev):
             m = ident.copy()
             m[[3, 7, 11]] = d
             mats.append(m)
+        sx_, sy_, sz_ = shape_s[2], shape_s[1], shape_s[0]
+        mats.append(np.array([-1, 0, 0, sx_ - 1.25, 0, 1, 0, 0.5, 0, 0, 1, -0.75], dtype=f32))   # mirror in x: t falls with x
+        mats.append(np.array([1, 0, 0, 0, 0, -1, 0, sy_ - 1, 0, 0, -1, sz_ - 1], dtype=f32))      # t falls with y and z
+        mats.append(np.array([0, 1, 0, 0.3, 1, 0, 0, -0.2, 0, 0, 1, 0], dtype=f32))               # x and y swapped
+        mats.append(np.array([0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0], dtype=f32))                    # x and z swapped
+        mats.append(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 2.5], dtype=f32))                  # every z on one source plane
         mats.append(ident * f32(0.0))                       # everything maps to t = 0.5
         mats.append(np.full(12, 1e30, dtype=f32))           # overflows to inf / nan: all out of the window
         mats.append(np.full(12, np.nan, dtype=f32))
@@ -241,7 +247,7 @@ def test_padded_cost_kernel_is_bit_identical(dev):
                 b = dev.corr_sums(dt, pad, m)
                 assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"{shape_s} matrix {i}, kernel {kern}"
             dev.corr_padded_force_kernel(-1)
-            if i < 11:
+            if i < 16:
                 wss, wst = ro.corr_sums(tgt, src, m)
                 assert abs(b[0] - wss) <= 1e-12 * max(wss, 1e-30) and abs(b[1] - wst) <= 1e-11 * max(wss, 1e-30)
         pad.close()
