@@ -467,7 +467,7 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
     constexpr int kMemo = 32;  // 4 entries catch the start-of-line repeats (9 % of the evaluations), 32 another 2.5 %
     Memo memo[kMemo];
     int memo_n = 0, memo_next = 0;
-    static const bool memo_off = getenv("MIL_REG_NOMEMO") && getenv("MIL_REG_NOMEMO")[0] == '1';
+    const bool memo_off = getenv("MIL_REG_NOMEMO") && getenv("MIL_REG_NOMEMO")[0] == '1';  // per call: the tests flip it
     CostFn cost = [&](const float *x) -> float {  // costfunc :2377-2388 + corrfunc :954-988
         if (dof9) dof9tomatrix(aff.m, x, dof_num);
         else p2matrix(aff.m, x);

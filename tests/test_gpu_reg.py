@@ -390,6 +390,22 @@ def test_full_size_registration_properties(dev):
     assert np.allclose(tmx, ident, atol=0.05)
 
 
+def test_memo_of_repeated_evaluations_changes_nothing(dev, monkeypatch):
+    """Powell re-evaluates points it has just visited; reg3d answers those from its last 32 results instead of another
+    pass over the volumes (csrc/reg.cpp).  Same matrix, same ZNCC, same evaluation count as with the memo off -- only the
+    number of kernel launches differs."""
+    g = np.load(os.path.join(GOLD, "reg3d.npz"))
+    tgt, src = T(g["tgt"]), T(g["src"])
+    _, tmx, rec = dev.reg3d_affine(tgt, src, aff_method=6, it_limit=600)
+    launches = dev.reg3d_last_cost_launches()
+    monkeypatch.setenv("MIL_REG_NOMEMO", "1")
+    _, tmx2, rec2 = dev.reg3d_affine(tgt, src, aff_method=6, it_limit=600)
+    launches2 = dev.reg3d_last_cost_launches()
+    assert np.array_equal(tmx.view(np.uint32), tmx2.view(np.uint32))
+    assert rec[3] == rec2[3] and rec[5] == rec2[5] and rec[1] == rec2[1]
+    assert launches < launches2 == int(rec2[5])  # without the memo every evaluation launches
+
+
 def test_texture_weight_emulation_switch(dev, api):
     """mil_set_texture_weight_bits(8) / MIL_TEX_WEIGHT_BITS=8: interpolation weights rounded to 8 fractional bits like
     the CUDA texture unit the reference samples through (include/cukernel.cuh:510-522, 545-546).
