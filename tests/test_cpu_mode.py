@@ -111,6 +111,20 @@ def test_config1_dual_view_and_threads(api, monkeypatch):
     assert np.array_equal(one, four)  # every pass is element-wise or per-column: threads do not change a bit
 
 
+def test_dual_view_unmatched_back_projectors(api):
+    shape = (24, 40, 44)
+    psf_a = do.gaussian_psf((9, 9, 9), (2.0, 1.2, 1.2))
+    psf_b = do.gaussian_psf((9, 9, 9), (1.2, 1.2, 2.0))
+    bp_a = do.gaussian_psf((9, 9, 9), (1.2, 1.0, 1.0))
+    bp_b = do.gaussian_psf((9, 9, 9), (1.0, 1.0, 1.2))
+    img_a = do.synthetic_view(shape, psf_a, seed=5, noise_seed=6, n_blobs=10)
+    img_b = do.synthetic_view(shape, psf_b, seed=5, noise_seed=7, n_blobs=10)
+    out, rec = api.decon_dualview(img_a, img_b, psf_a, psf_b, 4, gpu_mem_mode=0, unmatch=True, psf_bp1=bp_a, psf_bp2=bp_b)
+    assert rec[0] == 0
+    want = do.decon_dualview(img_a, img_b, psf_a, psf_b, 4, unmatch=True, psf_bp1=bp_a, psf_bp2=bp_b)
+    assert rel_err(out, want) < RTOL
+
+
 @pytest.mark.parametrize("shape", [(20, 36, 50), (33, 130, 300)])
 def test_ragged_sizes_pad_and_crop(api, shape):
     psf = do.gaussian_psf((11, 11, 11), (2.0, 1.3, 1.3))
