@@ -17,7 +17,8 @@ namespace {
 
 constexpr int kW = 16;  // columns per tile: 16 complex = one 128-byte line pair of the interleaved spectrum
 
-#define MIL_CPU_CLONES __attribute__((target_clones("arch=skylake-avx512", "arch=haswell", "default")))
+// feature-based clones: the resolver tests CPU features (Intel and AMD alike), not a vendor model name
+#define MIL_CPU_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
 
 struct Stage {
     int r, m, s;                 // radix, n_cur / r, stride (product of the radices before)
