@@ -322,8 +322,9 @@ def main():
         pipe = batch.FusionPipeline(SHAPE, psf_a, psf_b, iters=20)
         n_tp = args.batch_time_points_per_gpu * world
         pol = lambda: batch.RegPolicy(reg_mode=3, reg_choice=2, aff_method=6, ftol=1e-4, it_limit=3000)
+        # overlap: the joint RL of time point i runs on a helper thread / its own stream while i + 1 is registered
         run = lambda tps: batch.run_sharded(tps, lambda t: (img_a, view_b), pipe.fuse_pair, pol(), pipe.reg_fn,
-                                            pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev)
+                                            pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev, overlap=True)
         run(list(range(world)))  # warm-up: one time point per rank
         fence()
         tb = time.perf_counter()

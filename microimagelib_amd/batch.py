@@ -145,11 +145,14 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
                 fuse_pair: Callable[[object, object, int], Tuple[object, torch.Tensor]],
                 policy: RegPolicy, reg_fn: RegFn, check_fn: CheckFn, mip_shape: Tuple[int, int],
                 sink: Optional[Callable[[int, object, np.ndarray, np.ndarray], None]] = None,
-                device="cpu", group=None) -> Optional[torch.Tensor]:
+                device="cpu", group=None, overlap: bool = False) -> Optional[torch.Tensor]:
     """Run the batch over this rank's share of `time_points`.
 
     load_pair(t) -> (view A, view B) already resized / rotated; fuse_pair(A, B_registered, t) -> (decon, XY MIP);
     sink(t, decon, tmx, reg_records) persists per-time-point outputs (rank-local, no exchange).
+    overlap: deconvolution + sink of time point i run on a helper thread while this thread loads and registers time point
+    i + 1 (independent streams on the GPU: the deconvolution fills the gaps between Powell's cost evaluations); results
+    are the same, only the order of host-side side effects within a rank changes.  Modes 0, 1, 3.
     Returns the time-ordered MIP stack on rank 0."""
     rank, world = _world(group)
     time_points = list(time_points)
@@ -166,13 +169,37 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
         policy = RegPolicy(reg_mode=0, reg_choice=0, aff_method=policy.aff_method, ftol=policy.ftol,
                            it_limit=policy.it_limit, cost_bar=policy.cost_bar, i_tmx=tmx)
     local: Dict[int, torch.Tensor] = {}
-    for i, t in enumerate(shard_time_points(time_points, rank, world)):
-        a, b = load_pair(t)
-        b_reg, tmx, rec = register_pair(policy, reg_fn, check_fn, a, b, first=(i == 0))
+
+    def finish(a, b_reg, t, tmx, rec):
         decon, mip = fuse_pair(a, b_reg, t)
-        local[t] = mip
+        local[t] = mip.clone() if overlap else mip
         if sink is not None:
             sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
+
+    worker, pending = None, None
+    if overlap:
+        import concurrent.futures
+        dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def init_worker():  # the current device is per thread
+            if dev_index is not None:
+                torch.cuda.set_device(dev_index)
+        worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=init_worker)
+    try:
+        for i, t in enumerate(shard_time_points(time_points, rank, world)):
+            a, b = load_pair(t)
+            b_reg, tmx, rec = register_pair(policy, reg_fn, check_fn, a, b, first=(i == 0))
+            if worker is None:
+                finish(a, b_reg, t, tmx, rec)
+            else:
+                if pending is not None:
+                    pending.result()  # one deconvolution in flight: the pipeline owns one estimate buffer
+                pending = worker.submit(finish, a, b_reg, t, tmx, rec)
+        if pending is not None:
+            pending.result()
+    finally:
+        if worker is not None:
+            worker.shutdown(wait=True)
     return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
 
 

@@ -75,11 +75,26 @@ void *pool_alloc(size_t bytes) {
     return p;
 }
 
+namespace {
+void give_back(void *p) noexcept;
+}
+
 void pool_free(void *p) noexcept {
     if (!p) return;
-    Pool &pl = pool();
     // hipFree waits for the device; callers rely on that (a buffer may go out of scope behind work still queued)
     (void)hipDeviceSynchronize();
+    give_back(p);
+}
+
+void pool_free_after(void *p, hipStream_t s) noexcept {
+    if (!p) return;
+    (void)hipStreamSynchronize(s);
+    give_back(p);
+}
+
+namespace {
+void give_back(void *p) noexcept {
+    Pool &pl = pool();
     std::lock_guard<std::mutex> lock(pl.mu);
     auto it = pl.live.find(p);
     if (it == pl.live.end()) {
@@ -95,6 +110,7 @@ void pool_free(void *p) noexcept {
     pl.free_blocks[{b.device, b.bytes}].push_back(p);
     pl.cached_bytes += b.bytes;
 }
+}  // namespace
 
 size_t pool_release_all() {
     Pool &pl = pool();

@@ -41,7 +41,8 @@ inline long long div_up(long long a, long long b) { return (a + b - 1) / b; }
 
 // Device allocations go through a pool that keeps freed blocks for the next call of the same size (devpool.cpp).
 void *pool_alloc(size_t bytes);
-void pool_free(void *p) noexcept;
+void pool_free(void *p) noexcept;               // waits for the whole device first, like hipFree
+void pool_free_after(void *p, hipStream_t s) noexcept;  // waits for `s` only: the caller knows no other stream uses p
 size_t pool_release_all();  // hipFree everything cached; returns the bytes given back
 
 // RAII device buffer.
@@ -65,6 +66,13 @@ public:
     }
     void release() {
         if (p_) pool_free(p_);
+        p_ = nullptr;
+        n_ = 0;
+    }
+    // for a buffer only ever used on stream `s`: does not stall on other streams' work (a time-lapse host overlaps the
+    // deconvolution of one time point with the registration of the next)
+    void release_after(hipStream_t s) {
+        if (p_) pool_free_after(p_, s);
         p_ = nullptr;
         n_ = 0;
     }

@@ -450,7 +450,7 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
                         !(getenv("MIL_CORR_UNPADDED") && getenv("MIL_CORR_UNPADDED")[0] == '1');
     if (padded) {
         src_pad.build(src_ms.get(), dims, stream);
-        src_ms.release();
+        src_ms.release_after(stream);  // only this stream ever touched it
     }
 
     int evals = 0, launches = 0;

@@ -150,6 +150,50 @@ def test_chained_mode_three_ranks_carries_the_running_average(tmp_path):
     assert [len(r["log"]) for r in rs] == [2, 2, 1]  # 5 time points dealt 3, 4, 5, 6, 7 -> ranks 0, 1, 2, 0, 1
 
 
+def test_overlapped_pipeline_gives_the_same_results():
+    """overlap=True: fuse + sink of time point i on a helper thread while i + 1 registers -- same matrices, same MIPs,
+    every time point sunk exactly once, and the helper really ran concurrently with a registration."""
+    import threading
+    import time as _time
+
+    def run(overlap):
+        log, sunk, seen = [], {}, {"concurrent": False, "registering": False}
+
+        def reg_fn(target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
+            seen["registering"] = True
+            _time.sleep(0.02)
+            seen["registering"] = False
+            tmx = np.eye(3, 4, dtype=np.float32).reshape(12)
+            tmx[3] = float(target)
+            rec = np.zeros(11, dtype=np.float32)
+            rec[3] = 0.9
+            log.append(int(target))
+            return source, tmx, rec
+
+        def fuse_pair(a, b_reg, t):
+            for _ in range(20):
+                if seen["registering"]:
+                    seen["concurrent"] = True
+                _time.sleep(0.002)
+            return None, torch.full(MIP_SHAPE, float(10 * t + 1))
+
+        def sink(t, decon, tmx, rec):
+            assert t not in sunk
+            sunk[t] = (tmx.tolist(), threading.current_thread().name)
+        stack = batch.run_sharded([3, 4, 5, 6], lambda t: (t, t), fuse_pair, batch.RegPolicy(reg_mode=3, reg_choice=2),
+                                  reg_fn, lambda m: True, MIP_SHAPE, sink=sink, overlap=overlap)
+        return log, sunk, stack, seen["concurrent"]
+
+    log0, sunk0, stack0, conc0 = run(False)
+    log1, sunk1, stack1, conc1 = run(True)
+    assert log0 == log1 == [3, 4, 5, 6]
+    assert {t: v[0] for t, v in sunk0.items()} == {t: v[0] for t, v in sunk1.items()}
+    assert torch.equal(stack0, stack1)
+    assert not conc0 and conc1
+    assert all(v[1] == threading.current_thread().name for v in sunk0.values())
+    assert all(v[1] != threading.current_thread().name for v in sunk1.values())
+
+
 def test_fallback_ladder_matches_reference():
     """Low ZNCC on the first attempt -> other scheme without input matrix -> input matrix (regChoice 0)."""
     calls = []
