@@ -102,36 +102,31 @@ void gen_otf(const Rfft3D &fft, float2 *otf, const float *psf, Dims p, bool flip
     const double sum = sum_f64(psf, n_psf, 1);
     const float scale = (float)(1.0 / sum);  // (float)(1 / sumValue)  :1659
     std::memset(work, 0, n_box * sizeof(float));
-    // effective PSF after the optional centre crop: extents e = min(p, F), source offset c (crop) per axis
-    const long long ex = std::min(p.nx, F.nx), ey = std::min(p.ny, F.ny), ez = std::min(p.nz, F.nz);
-    auto crop_off = [](long long s, long long Fd) { return s > Fd ? -((Fd - s) / 2) : 0; };  // (F-s)/2 truncates to 0
-    const long long cx = crop_off(p.nx, F.nx), cy = crop_off(p.ny, F.ny), cz = crop_off(p.nz, F.nz);
-    // When an axis is cropped the PSF box becomes the FFT box (padPSF with s == F: origin F/2), and the align step
-    // zero-pads the other axes to F too (offset (F - s)/2): the origin of an uncropped axis is then (F-s)/2 + ... --
-    // alignsize3D places the whole PSF centred in the box before the origin shift.
+    // Per axis (PSF extent s, box extent S), for index i of the (flipped) PSF:
+    //   no axis larger than the box:   destination (i - s/2) mod S                       (padPSF, origin s/2)
+    //   some axis larger than the box: the PSF is first centred in the box -- alignsize3D: cropped at offset (s - S)/2
+    //                                  where s > S, zero-padded at offset (S - s)/2 where s < S -- then shifted by S/2.
     const bool cropped = p.nx > F.nx || p.ny > F.ny || p.nz > F.nz;
-    for (long long z = 0; z < ez; ++z)
-        for (long long y = 0; y < ey; ++y)
-            for (long long x = 0; x < ex; ++x) {
-                const long long sx = x + cx, sy = y + cy, sz = z + cz;  // index in the (flipped) PSF
-                const long long fx = flip ? p.nx - 1 - sx : sx, fy = flip ? p.ny - 1 - sy : sy,
-                                fz = flip ? p.nz - 1 - sz : sz;
-                const float v = psf[(fz * p.ny + fy) * p.nx + fx] * scale;
-                long long dx, dy, dz;
-                if (cropped) {
-                    // aligned box coordinates: a = index - c + max((F - s) / 2, 0), then origin shift by F / 2
-                    const long long ax = sx - cx + (p.nx < F.nx ? (F.nx - p.nx) / 2 : 0);
-                    const long long ay = sy - cy + (p.ny < F.ny ? (F.ny - p.ny) / 2 : 0);
-                    const long long az = sz - cz + (p.nz < F.nz ? (F.nz - p.nz) / 2 : 0);
-                    dx = ax - F.nx / 2; dy = ay - F.ny / 2; dz = az - F.nz / 2;
-                } else {
-                    dx = sx - p.nx / 2; dy = sy - p.ny / 2; dz = sz - p.nz / 2;
-                }
-                if (dx < 0) dx += F.nx;
-                if (dy < 0) dy += F.ny;
-                if (dz < 0) dz += F.nz;
-                work[(dz * F.ny + dy) * F.nx + dx] = v;
+    struct Axis {
+        long long first, count, shift;  // PSF indices [first, first + count) survive; destination = (i + shift) mod S
+    };
+    auto axis = [&](long long s, long long S) {
+        if (!cropped) return Axis{0, s, -(s / 2)};
+        if (s > S) return Axis{(s - S) / 2, S, -((s - S) / 2) - S / 2};
+        return Axis{0, s, (S - s) / 2 - S / 2};
+    };
+    const Axis ax = axis(p.nx, F.nx), ay = axis(p.ny, F.ny), az = axis(p.nz, F.nz);
+    auto wrap = [](long long d, long long S) { return ((d % S) + S) % S; };
+    for (long long z = az.first; z < az.first + az.count; ++z) {
+        const long long fz = flip ? p.nz - 1 - z : z, dz = wrap(z + az.shift, F.nz);
+        for (long long y = ay.first; y < ay.first + ay.count; ++y) {
+            const long long fy = flip ? p.ny - 1 - y : y, dy = wrap(y + ay.shift, F.ny);
+            for (long long x = ax.first; x < ax.first + ax.count; ++x) {
+                const long long fx = flip ? p.nx - 1 - x : x, dx = wrap(x + ax.shift, F.nx);
+                work[(dz * F.ny + dy) * F.nx + dx] = psf[(fz * p.ny + fy) * p.nx + fx] * scale;
             }
+        }
+    }
     fft.forward(work, otf);
 }
 
