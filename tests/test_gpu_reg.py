@@ -396,6 +396,7 @@ def test_memo_of_repeated_evaluations_changes_nothing(dev, monkeypatch):
     number of kernel launches differs."""
     g = np.load(os.path.join(GOLD, "reg3d.npz"))
     tgt, src = T(g["tgt"]), T(g["src"])
+    monkeypatch.delenv("MIL_REG_NOMEMO", raising=False)
     _, tmx, rec = dev.reg3d_affine(tgt, src, aff_method=6, it_limit=600)
     launches = dev.reg3d_last_cost_launches()
     monkeypatch.setenv("MIL_REG_NOMEMO", "1")
