@@ -150,9 +150,11 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
 
     load_pair(t) -> (view A, view B) already resized / rotated; fuse_pair(A, B_registered, t) -> (decon, XY MIP);
     sink(t, decon, tmx, reg_records) persists per-time-point outputs (rank-local, no exchange).
-    overlap: deconvolution + sink of time point i run on a helper thread while this thread loads and registers time point
-    i + 1 (independent streams on the GPU: the deconvolution fills the gaps between Powell's cost evaluations); results
-    are the same, only the order of host-side side effects within a rank changes.  Modes 0, 1, 3.
+    overlap: deconvolution + sink of time point i run on a helper thread while this thread registers time point i + 1
+    (independent streams on the GPU: the deconvolution fills the gaps between Powell's cost evaluations), and
+    load_pair(i + 2) runs on a second helper thread (file decode + upload hidden behind the registration; load_pair must
+    hand out buffers that stay valid for two calls).  Results are the same, only the order of host-side side effects
+    within a rank changes.  Modes 0, 1, 3.
     Returns the time-ordered MIP stack on rank 0."""
     rank, world = _world(group)
     time_points = list(time_points)
@@ -176,7 +178,8 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
         if sink is not None:
             sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
 
-    worker, pending = None, None
+    worker, loader, pending, ahead = None, None, None, None
+    mine = shard_time_points(time_points, rank, world)
     if overlap:
         import concurrent.futures
         dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
@@ -185,9 +188,16 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
             if dev_index is not None:
                 torch.cuda.set_device(dev_index)
         worker = concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=init_worker)
+        loader = concurrent.futures.ThreadPoolExecutor(max_workers=1, initializer=init_worker)
+        if mine:
+            ahead = loader.submit(load_pair, mine[0])
     try:
-        for i, t in enumerate(shard_time_points(time_points, rank, world)):
-            a, b = load_pair(t)
+        for i, t in enumerate(mine):
+            if loader is None:
+                a, b = load_pair(t)
+            else:
+                a, b = ahead.result()
+                ahead = loader.submit(load_pair, mine[i + 1]) if i + 1 < len(mine) else None
             b_reg, tmx, rec = register_pair(policy, reg_fn, check_fn, a, b, first=(i == 0))
             if worker is None:
                 finish(a, b_reg, t, tmx, rec)
@@ -198,8 +208,9 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
         if pending is not None:
             pending.result()
     finally:
-        if worker is not None:
-            worker.shutdown(wait=True)
+        for ex in (worker, loader):
+            if ex is not None:
+                ex.shutdown(wait=True)
     return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
 
 

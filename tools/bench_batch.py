@@ -99,8 +99,11 @@ def main():
             for name, base in (("SPIMA", base_a), ("SPIMB", base_b)):
                 vol = (base + torch.randn(base.shape, device="cuda", generator=g) * 3.0).clamp_(0, 65535)
                 api.writetifstack(os.path.join(tiff_dir, f"{name}_{k}.tif"), vol.cpu().numpy(), bits=16)
-        tiff_in = torch.empty((2,) + shape, dtype=torch.float32).pin_memory()
+        tiff_in = torch.empty((2, 2) + shape, dtype=torch.float32).pin_memory()  # two sets: --overlap reads one time point ahead
         tiff_out = torch.empty(shape, dtype=torch.float32).pin_memory()
+        tiff_calls = [0]
+
+    load_stream = torch.cuda.Stream()
 
     def dev_sync():  # per-phase seconds need a device-wide wait; with --overlap that would serialise the two threads
         if not args.overlap:
@@ -111,10 +114,13 @@ def main():
         g = torch.Generator(device="cuda").manual_seed(1000 + t)
         if tiff_dir:
             k = t % args.tiff_files
+            buf = tiff_in[tiff_calls[0] % 2]
+            tiff_calls[0] += 1
             for i, name in enumerate(("SPIMA", "SPIMB")):  # decode straight into pinned memory, then one DMA each
-                api.readtifstack(os.path.join(tiff_dir, f"{name}_{k}.tif"), out=tiff_in[i].numpy())
-            a, b = tiff_in[0].cuda(non_blocking=True), tiff_in[1].cuda(non_blocking=True)
-            torch.cuda.synchronize()
+                api.readtifstack(os.path.join(tiff_dir, f"{name}_{k}.tif"), out=buf[i].numpy())
+            with torch.cuda.stream(load_stream):
+                a, b = buf[0].cuda(non_blocking=True), buf[1].cuda(non_blocking=True)
+            load_stream.synchronize()
             split["load"] += time.perf_counter() - t0
             return a, b
         if args.host:
