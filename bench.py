@@ -222,7 +222,15 @@ def main():
         # Kernel families timed with HIP events on the engine's stream inside the timed region, with the
         # ALGORITHMIC bytes one launch must move (R = real volume, C = half spectrum [nz][ny][nx/2+1] complex64;
         # DESIGN.md "Kernels").  Fused backend: every family is one hand-written kernel.
-        if fused:
+        two_pass = fused and getattr(eng, "two_pass", 0) == 3
+        if two_pass:  # csrc/fft2p.hip: the y transform rides in the z kernel (its last stage) and in the x kernel
+            fam = {
+                "xy_update (y head^-1, x^-1, E=max(E*T,0.01), x, y head fused)": (upd_ms, upd_n, 2 * C + 2 * R),
+                "xy_ratio (y head^-1, x^-1, T=A/T, x, y head fused)": (rat_ms, rat_n, 2 * C + R),
+                "yz_conv (y tail, z, *OTF, z^-1, y tail^-1 fused)": (cm_ms, cm_n, 3 * C),
+            }
+            iter_bytes = 10 * C + 3 * R
+        elif fused:
             fam = {
                 "x_update (x^-1, E=max(E*T,0.01), x fused)": (upd_ms, upd_n, 2 * C + 2 * R),
                 "x_ratio (x^-1, T=A/T, x fused)": (rat_ms, rat_n, 2 * C + R),
@@ -238,10 +246,10 @@ def main():
                 "rocfft_execute (library 3-D real transform, 3-4 kernels)": (fft_ms, fft_n, R + C),
             }
             iter_bytes = 4 * (R + C) + 2 * 3 * C + 3 * R + 3 * R
-        upd_key = [k for k in fam if k.startswith(("x_update", "rl_update"))][0]
+        upd_key = [k for k in fam if k.startswith(("x_update", "xy_update", "rl_update"))][0]
         upd_frac = (round(fam[upd_key][2] / (upd_ms / upd_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     if upd_n and upd_ms > 0 else None)
-        dom = [k for k in fam if k.startswith("z_conv" if fused else "cmul_otf")][0]
+        dom = [k for k in fam if k.startswith(("yz_conv", "z_conv") if fused else "cmul_otf")][0]
         dom_bytes = fam[dom][2]
         dom_avg_ms = dom_ms / max(dom_n, 1)  # measured inside the timed region
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_n else None
@@ -270,7 +278,7 @@ def main():
             "config": {
                 "workload": "deconSingleView 512x512x256 float32, RL iterations, 1 MI355X (BASELINE.json configs[1])",
                 "psf": "64x64x64 anisotropic Gaussian, matched back projector",
-                "backend": "fused" if fused else "rocfft",
+                "backend": ("fused, two passes per convolution" if two_pass else "fused") if fused else "rocfft",
                 "volumes_per_gpu": 1,
                 "sharding": "one time-point volume per GPU, no data-path collective; XY-MIP gather over RCCL after the timed region",
             },

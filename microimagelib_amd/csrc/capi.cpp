@@ -162,6 +162,7 @@ int mil_decon_create_backend(mil_decon **out, int nx, int ny, int nz, void *stre
     });
 }
 int mil_decon_backend(const mil_decon *e) { return e->engine.backend(); }
+int mil_decon_two_pass(const mil_decon *e) { return e->engine.two_pass(); }
 int mil_decon_convolve(mil_decon *e, float *d_out, const float *d_in, const void *d_otf) {
     return guarded("mil_decon_convolve", [&] { e->engine.convolve(d_out, d_in, (const float2 *)d_otf); return 0; });
 }

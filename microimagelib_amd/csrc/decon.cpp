@@ -139,7 +139,13 @@ DeconEngine::DeconEngine(Dims fft_box, hipStream_t stream, int backend) : box_(f
         own_stream_ = true;
     }
     try {
-        if (backend == kBackendFused) plan_ = new fx::ConvPlan(box_);
+        if (backend == kBackendFused) {
+            plan_ = new fx::ConvPlan(box_);
+            if (plan_->two_pass()) {  // MIL_FX_TWOPASS: 0 classic, 1 z kernel only, 2 x kernel only, 3 both
+                const char *tp = getenv("MIL_FX_TWOPASS");
+                two_pass_ = tp ? (atoi(tp) & 3) : kTwoPassDefault;
+            }
+        }
         else fft_ = new Fft3D(box_, stream_);
         T_.alloc(real_count());
         S_.alloc(spectrum_count());
@@ -250,6 +256,52 @@ void DeconEngine::enqueue_iteration(float *E, const float *const *M, const float
                                     const float2 *const *otf_bp, int views, bool last_iteration) {
     static const bool pingpong = !(getenv("MIL_FX_PINGPONG") && !strcmp(getenv("MIL_FX_PINGPONG"), "0"));
     float2 *S = S_.get();
+    if (two_pass_) {
+        // Two-pass path (csrc/fft2p.hip): S carries the y HEAD (the stages longer than 8) between kernels; the y tail
+        // rides in the z kernel (bit 0) and the head in the x kernel (bit 1).  With one bit only, classic partial y passes
+        // fill in for the other kernel (test / bisect configurations).
+        const bool yz = two_pass_ & 1, xy = two_pass_ & 2;
+        for (int v = 0; v < views; ++v) {
+            const bool last = last_iteration && (v == views - 1);
+            for (int half = 0; half < 2; ++half) {
+                const float2 *o = half == 0 ? otf[v] : otf_bp[v];
+                if (!yz) {
+                    timers[kTimeFft].begin(stream_);
+                    plan_->y_part(S, 2, stream_);
+                    timers[kTimeFft].end(stream_);
+                }
+                timers[kTimeCmul].begin(stream_);
+                if (yz) plan_->yz_conv(S, o, stream_);
+                else plan_->z_conv(S, o, stream_, false);
+                timers[kTimeCmul].end(stream_);
+                if (!yz) {
+                    timers[kTimeFft].begin(stream_);
+                    plan_->y_part(S, 3, stream_);
+                    timers[kTimeFft].end(stream_);
+                }
+                const fx::XMode mode = half == 0 ? fx::kXRatio : (last ? fx::kXUpdateLast : fx::kXUpdate);
+                const int t = half == 0 ? kTimeRatio : kTimeUpdate;
+                if (xy) {
+                    timers[t].begin(stream_);
+                    plan_->xy_pass(mode, S, E, M[v], kSmallValue, stream_);
+                    timers[t].end(stream_);
+                } else {
+                    timers[kTimeFft].begin(stream_);
+                    plan_->y_part(S, 1, stream_);
+                    timers[kTimeFft].end(stream_);
+                    timers[t].begin(stream_);
+                    plan_->x_pass(mode, S, nullptr, half == 0 ? nullptr : E, half == 0 ? M[v] : nullptr, kSmallValue, stream_, false);
+                    timers[t].end(stream_);
+                    if (mode != fx::kXUpdateLast) {
+                        timers[kTimeFft].begin(stream_);
+                        plan_->y_part(S, 0, stream_);
+                        timers[kTimeFft].end(stream_);
+                    }
+                }
+            }
+        }
+        return;
+    }
     bool dir = false;  // direction of the most recent z-ordered kernel (the x pass that produced S)
     auto next_dir = [&] { dir = pingpong ? !dir : false; return dir; };
     for (int v = 0; v < views; ++v) {
@@ -282,6 +334,7 @@ void DeconEngine::run_fused(float *E, const float *const *M, const float2 *const
                             int views, int iters) {
     if (iters <= 0) return;
     plan_->x_pass(fx::kXForward, S_.get(), E, nullptr, nullptr, 0.f, stream_, false);
+    if (two_pass_) plan_->y_part(S_.get(), 0, stream_);
     // Plain asynchronous launches.  Replaying one captured iteration as a HIP graph was measured and dropped:
     // 918 vs 915 it/s at 512x512x256 (kernels of 90-170 us hide the launches anyway) and SLOWER on small boxes
     // (64^3: 19.9k vs 27.1k it/s -- a replay costs more than eight queued launches).

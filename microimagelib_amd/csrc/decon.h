@@ -73,6 +73,8 @@ public:
     Dims box() const { return box_; }
     size_t real_count() const { return (size_t)box_.count(); }
     int backend() const { return plan_ ? kBackendFused : kBackendRocfft; }
+    // fused backend: 0 classic four-kernel half update, 3 two-pass (csrc/fft2p.hip), 1 / 2 mixed (tests)
+    int two_pass() const { return two_pass_; }
     size_t natural_spectrum_count() const { return (size_t)(box_.nx / 2 + 1) * box_.ny * box_.nz; }
     // complex64 elements of a spectrum / OTF buffer of this engine (layout is backend-private)
     size_t spectrum_count() const { return plan_ ? plan_->spectrum_count() : natural_spectrum_count(); }
@@ -103,6 +105,8 @@ private:
     bool own_stream_ = false;
     Fft3D *fft_ = nullptr;          // rocFFT backend
     fx::ConvPlan *plan_ = nullptr;  // fused backend
+    int two_pass_ = 0;              // fused backend, 512 x 512 x 256 boxes: bit 0 yz kernel, bit 1 xy kernel (csrc/fft2p.hip)
+    static constexpr int kTwoPassDefault = 3;
     void run_fused(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp, int views,
                    int iters);
     void enqueue_iteration(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp,

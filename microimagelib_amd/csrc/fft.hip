@@ -24,207 +24,7 @@ namespace fx {
 
 namespace {
 
-constexpr int kW = 16;    // tile width in complex columns (128 B)
-constexpr int kWP = 17;   // LDS row stride in float2
-constexpr int kNT = 256;  // threads per workgroup
-constexpr int kBatch = 8; // float4 loads in flight per lane while staging
-
-__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {  // a * conj(b)
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-// tables hold w = exp(-2*pi*i*k/n); SIGN = -1 uses w, SIGN = +1 uses conj(w)
-template <int SIGN>
-__device__ __forceinline__ float2 tw_mul(float2 a, float2 w) {
-    return SIGN < 0 ? c_mul(a, w) : c_mulc(a, w);
-}
-// multiply by SIGN * i
-template <int SIGN>
-__device__ __forceinline__ float2 rot90(float2 a) {
-    return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
-}
-
-template <int SIGN>
-__device__ __forceinline__ void dft2(float2 *v) {
-    float2 a = v[0], b = v[1];
-    v[0] = c_add(a, b);
-    v[1] = c_sub(a, b);
-}
-
-template <int SIGN>
-__device__ __forceinline__ void dft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3) {
-    float2 a0 = c_add(v0, v2), a1 = c_sub(v0, v2);
-    float2 a2 = c_add(v1, v3), a3 = rot90<SIGN>(c_sub(v1, v3));
-    v0 = c_add(a0, a2);
-    v2 = c_sub(a0, a2);
-    v1 = c_add(a1, a3);
-    v3 = c_sub(a1, a3);
-}
-
-template <int SIGN>
-__device__ __forceinline__ void dft8(float2 *v) {
-    constexpr float h = 0.70710678118654752440f;
-    dft4<SIGN>(v[0], v[2], v[4], v[6]);  // even part, outputs E[0..3] in v0,v2,v4,v6
-    dft4<SIGN>(v[1], v[3], v[5], v[7]);  // odd part,  outputs O[0..3] in v1,v3,v5,v7
-    float2 o1 = v[3], o2 = v[5], o3 = v[7];
-    // w8^1, w8^2, w8^3 with w8 = exp(SIGN*i*pi/4)
-    if (SIGN < 0) {
-        o1 = make_float2((o1.x + o1.y) * h, (o1.y - o1.x) * h);
-        o3 = make_float2((o3.y - o3.x) * h, (-o3.y - o3.x) * h);
-    } else {
-        o1 = make_float2((o1.x - o1.y) * h, (o1.x + o1.y) * h);
-        o3 = make_float2((-o3.x - o3.y) * h, (o3.x - o3.y) * h);
-    }
-    o2 = rot90<SIGN>(o2);
-    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
-    v[0] = c_add(e0, o0);
-    v[4] = c_sub(e0, o0);
-    v[1] = c_add(e1, o1);
-    v[5] = c_sub(e1, o1);
-    v[2] = c_add(e2, o2);
-    v[6] = c_sub(e2, o2);
-    v[3] = c_add(e3, o3);
-    v[7] = c_sub(e3, o3);
-}
-
-// cos / sin(2*pi*k/R) for the odd radices
-template <int R>
-struct OddTable;
-template <>
-struct OddTable<3> {
-    static constexpr float c[3] = {1.0f, -0.49999999999999978f, -0.50000000000000044f};
-    static constexpr float s[3] = {0.0f, 0.86602540378443871f, -0.86602540378443837f};
-};
-template <>
-struct OddTable<5> {
-    static constexpr float c[5] = {1.0f, 0.30901699437494745f, -0.80901699437494734f, -0.80901699437494756f, 0.30901699437494723f};
-    static constexpr float s[5] = {0.0f, 0.95105651629515353f, 0.58778525229247325f, -0.58778525229247303f, -0.95105651629515364f};
-};
-template <>
-struct OddTable<7> {
-    static constexpr float c[7] = {1.0f, 0.62348980185873359f, -0.22252093395631434f, -0.90096886790241903f, -0.90096886790241915f, -0.22252093395631459f, 0.62348980185873337f};
-    static constexpr float s[7] = {0.0f, 0.7818314824680298f, 0.97492791218182362f, 0.43388373911755823f, -0.43388373911755801f, -0.97492791218182362f, -0.78183148246802991f};
-};
-template <>
-struct OddTable<11> {
-    static constexpr float c[11] = {1.0f, 0.84125353283118121f, 0.41541501300188644f, -0.142314838273285f, -0.65486073394528499f, -0.95949297361449737f, -0.95949297361449748f, -0.65486073394528521f, -0.14231483827328523f, 0.41541501300188605f, 0.84125353283118121f};
-    static constexpr float s[11] = {0.0f, 0.54064081745559756f, 0.90963199535451833f, 0.9898214418809328f, 0.75574957435425827f, 0.28173255684142967f, -0.28173255684142939f, -0.75574957435425816f, -0.98982144188093268f, -0.90963199535451855f, -0.54064081745559744f};
-};
-template <>
-struct OddTable<13> {
-    static constexpr float c[13] = {1.0f, 0.88545602565320991f, 0.56806474673115592f, 0.12053668025532301f, -0.35460488704253545f, -0.74851074817110119f, -0.97094181742605201f, -0.97094181742605212f, -0.7485107481711013f, -0.3546048870425359f, 0.1205366802553232f, 0.56806474673115481f, 0.88545602565321002f};
-    static constexpr float s[13] = {0.0f, 0.46472317204376851f, 0.82298386589365635f, 0.99270887409805397f, 0.93501624268541483f, 0.66312265824079519f, 0.23931566428755768f, -0.23931566428755743f, -0.66312265824079497f, -0.93501624268541472f, -0.99270887409805397f, -0.82298386589365702f, -0.4647231720437684f};
-};
-
-// R-point DFT for odd prime R by definition, folded over conjugate pairs:
-//   out[k], out[R-k] = (v0 + sum_j (v_j + v_(R-j)) cos(jk)) +/- SIGN*i * sum_j (v_j - v_(R-j)) sin(jk)
-template <int R, int SIGN>
-__device__ __forceinline__ void dft_odd(float2 *v) {
-    constexpr int H = (R - 1) / 2;
-    float2 a[H], b[H];
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-        a[j] = c_add(v[j + 1], v[R - 1 - j]);
-        b[j] = c_sub(v[j + 1], v[R - 1 - j]);
-    }
-    const float2 v0 = v[0];
-    float2 sum = v0;
-#pragma unroll
-    for (int j = 0; j < H; ++j) sum = c_add(sum, a[j]);
-    v[0] = sum;
-#pragma unroll
-    for (int k = 1; k <= H; ++k) {
-        float2 p = v0, q = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const int e = ((j + 1) * k) % R;
-            p.x += a[j].x * OddTable<R>::c[e];
-            p.y += a[j].y * OddTable<R>::c[e];
-            q.x += b[j].x * OddTable<R>::s[e];
-            q.y += b[j].y * OddTable<R>::s[e];
-        }
-        const float2 iq = (SIGN > 0) ? make_float2(-q.y, q.x) : make_float2(q.y, -q.x);  // SIGN * i * q
-        v[k] = c_add(p, iq);
-        v[R - k] = c_sub(p, iq);
-    }
-}
-
-template <int R, int SIGN>
-__device__ __forceinline__ void dft_small(float2 *v) {
-    if constexpr (R == 8) dft8<SIGN>(v);
-    else if constexpr (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
-    else if constexpr (R == 2) dft2<SIGN>(v);
-    else dft_odd<R, SIGN>(v);
-}
-
-// One radix-R pass over sub-transforms of length L of an N x 16 tile.
-//   DIF: y_k = w_L^(i*k) * DFT_R(x)[k]      DIT: y = DFT_R( w_L^(i*k) * x_k )
-// Lane mapping: column fastest (16 lanes), then butterfly index.
-template <int N, int R, int L, bool DIT, int SIGN, int W = kW, int NT = kNT, int WP = W + 1>
-__device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float2 *__restrict__ tw) {
-    constexpr int M = L / R;            // butterflies per sub-transform
-    constexpr int NB = (N / R) * W;     // butterflies in the tile
-    constexpr int TWS = N / L;          // table step: w_L = w_N^(N/L)
-#pragma unroll
-    for (int it = 0; it < (NB + NT - 1) / NT; ++it) {
-        const int idx = it * NT + (int)threadIdx.x;
-        if ((NB % NT) != 0 && idx >= NB) break;
-        const int c = idx % W;
-        const int b = idx / W;
-        const int blk = b / M, i = b % M;
-        float2 *p = tile + (blk * L + i) * WP + c;
-        float2 v[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) v[j] = p[j * M * WP];
-        if (DIT && M > 1) {
-#pragma unroll
-            for (int k = 1; k < R; ++k) v[k] = tw_mul<SIGN>(v[k], tw[i * k * TWS]);
-        }
-        dft_small<R, SIGN>(v);
-        if (!DIT && M > 1) {
-#pragma unroll
-            for (int k = 1; k < R; ++k) v[k] = tw_mul<SIGN>(v[k], tw[i * k * TWS]);
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) p[j * M * WP] = v[j];
-    }
-}
-
-// Radix schedule of a length-L sub-transform: 8s first, then 4 / 2, then the odd primes of the
-// 64*k sizes snapTransformSize produces (192 = 8*8*3, 320 = 8*8*5, ... 960 = 8*8*3*5).
-constexpr int pick_radix(int L) {
-    return (L % 8 == 0) ? 8 : (L % 4 == 0) ? 4 : (L % 2 == 0) ? 2 : (L % 3 == 0) ? 3 : (L % 5 == 0) ? 5
-         : (L % 7 == 0) ? 7 : (L % 11 == 0) ? 11 : (L % 13 == 0) ? 13 : L;
-}
-template <int L>
-struct Radix {
-    static constexpr int value = pick_radix(L);
-};
-
-// Barrier contract: the tile must be complete (barrier done) on entry; on return every
-// stage has been followed by a barrier.
-template <int N, int L, int SIGN, int W = kW, int NT = kNT, int WP = W + 1>
-__device__ __forceinline__ void fft_dif(float2 *tile, const float2 *tw) {
-    if constexpr (L > 1) {
-        constexpr int R = Radix<L>::value;
-        fft_stage<N, R, L, false, SIGN, W, NT, WP>(tile, tw);
-        __syncthreads();
-        fft_dif<N, L / R, SIGN, W, NT, WP>(tile, tw);
-    }
-}
-template <int N, int L, int SIGN, int W = kW, int NT = kNT>
-__device__ __forceinline__ void fft_dit(float2 *tile, const float2 *tw) {
-    if constexpr (L > 1) {
-        constexpr int R = Radix<L>::value;
-        fft_dit<N, L / R, SIGN, W, NT>(tile, tw);
-        fft_stage<N, R, L, true, SIGN, W, NT>(tile, tw);
-        __syncthreads();
-    }
-}
+#include "fft_dev.h"
 
 // ---------------------------------------------------------------------------
 // y pass / z convolution: N x 16 column tiles
@@ -253,64 +53,6 @@ struct ColArgs {
     int col0_stride;  // ny
     int ablate;       // timing experiments only (MIL_FX_ABLATE & 16: skip the OTF product, & 32: skip both z transforms)
 };
-
-template <int N, int NT>
-__device__ __forceinline__ void tile_load(float2 *__restrict__ tile, const float2 *__restrict__ base, long long stride) {
-    constexpr int TOTAL = N * 8;  // float4 pieces
-#pragma unroll 1
-    for (int it0 = 0; it0 < TOTAL; it0 += NT * kBatch) {
-        float4 v[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * NT + (int)threadIdx.x;
-            if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(base + (long long)(idx >> 3) * stride + 2 * (idx & 7));
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * NT + (int)threadIdx.x;
-            if (idx < TOTAL) {
-                float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
-                q[0] = make_float2(v[j].x, v[j].y);
-                q[1] = make_float2(v[j].z, v[j].w);
-            }
-        }
-    }
-}
-
-template <int N, int NT>
-__device__ __forceinline__ void tile_store(const float2 *__restrict__ tile, float2 *__restrict__ base, long long stride) {
-    constexpr int TOTAL = N * 8;
-#pragma unroll 4
-    for (int idx = (int)threadIdx.x; idx < TOTAL; idx += NT) {
-        const float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
-        const float2 a = q[0], b = q[1];
-        *reinterpret_cast<float4 *>(base + (long long)(idx >> 3) * stride + 2 * (idx & 7)) = make_float4(a.x, a.y, b.x, b.y);
-    }
-}
-
-// tile[p][c] *= otf[p][c], otf tile contiguous [N][16]
-template <int N, int NT>
-__device__ __forceinline__ void tile_mul(float2 *__restrict__ tile, const float2 *__restrict__ otf) {
-    constexpr int TOTAL = N * 8;
-#pragma unroll 1
-    for (int it0 = 0; it0 < TOTAL; it0 += NT * kBatch) {
-        float4 v[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * NT + (int)threadIdx.x;
-            if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(otf + 2 * idx);
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * NT + (int)threadIdx.x;
-            if (idx < TOTAL) {
-                float2 *q = tile + (idx >> 3) * kWP + 2 * (idx & 7);
-                q[0] = c_mul(q[0], make_float2(v[j].x, v[j].y));
-                q[1] = c_mul(q[1], make_float2(v[j].z, v[j].w));
-            }
-        }
-    }
-}
 
 template <int N, int NT, int MODE>
 __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
@@ -342,7 +84,7 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
             if (idx < N * 8) o[j] = *reinterpret_cast<const float4 *>(a.otf + otf_tile + 2 * idx);
         }
     }
-    __syncthreads();
+    lds_barrier();
     if constexpr (MODE == kColInverse) {
         fft_dit<N, N, +1, kW, NT>(tile, tw);
         tile_store<N, NT>(tile, base, a.row_stride);
@@ -379,7 +121,7 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
                     qv[i] = make_float2(0.5f * (h0.x - hn.x), 0.5f * (h0.y - hn.y));
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < (N + NT - 1) / NT; ++i) {
                 const int k = i * NT + (int)threadIdx.x;
@@ -388,7 +130,7 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
                     a.otf_q_out[outer * N + k] = qv[i];
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         tile_store<N, NT>(tile, a.otf_out + otf_tile, kW);
         return;
@@ -420,14 +162,14 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
             tile_mul<N, NT>(tile, a.otf + otf_tile);
         }
         if (packed) {
-            __syncthreads();  // column 0 now holds P*G
+            lds_barrier();  // column 0 now holds P*G
 #pragma unroll
             for (int i = 0; i < (N + NT - 1) / NT; ++i) {
                 const int k = i * NT + (int)threadIdx.x;
                 if (k < N) tile[k * kWP] = c_add(tile[k * kWP], keep[i]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (!(a.ablate & 32)) fft_dit<N, N, +1, kW, NT>(tile, tw);
         tile_store<N, NT>(tile, base, a.row_stride);
     }
@@ -503,7 +245,7 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (!(a.ablate & 1)) fft_dif<NH, NH, +1, RB>(tile, tw);  // element n of z' now sits at position pos[n]
         // ---- real-space epilogue, 4 consecutive x per lane
         {
@@ -534,7 +276,7 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
             }
         }
         if constexpr (MODE == kXInverse || MODE == kXUpdateLast) return;
-        __syncthreads();
+        lds_barrier();
     } else {
         // ---- real rows -> packed complex at digit-reversed positions
         constexpr int TOTAL = RB * (NH / 2);
@@ -547,7 +289,7 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
                 const int idx = it0 + j * kNT + (int)threadIdx.x;
                 if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(src + 4 * idx);
             }
-            if (it0 == 0) __syncthreads();  // pos[] staged
+            if (it0 == 0) lds_barrier();  // pos[] staged
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 const int idx = it0 + j * kNT + (int)threadIdx.x;
@@ -558,7 +300,7 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     // ---- forward: packed complex FFT, then split into the Hermitian half spectrum
     if (!(a.ablate & 2)) fft_dit<NH, NH, -1, RB>(tile, tw);
@@ -794,6 +536,7 @@ ConvPlan::ConvPlan(Dims box) : box_(box) {
     };
     upload(neg_y_, negated(fy));
     upload(neg_z_, negated(fz));
+    init_two_pass();
 }
 
 void ConvPlan::x_pass(XMode mode, float2 *S, const float *rin, float *rout, const float *M, float eps,

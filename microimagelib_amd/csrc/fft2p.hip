@@ -1,0 +1,610 @@
+// Two passes per convolution instead of four (see fftconv.h, "two-pass path").
+//
+// The classic sequence of one half view update is  y | z-conv | y^-1 | [x^-1 . op . x]  -- four trips of the spectrum
+// through HBM.  The y transform of length 512 is three radix-8 stages; its LAST stage only combines 8 ADJACENT rows and
+// its first two only rows with the same y mod 8.  So the last stage moves into the z kernel and the first two into the
+// x kernel:
+//
+//   yz_conv_kernel   8 adjacent rows x 16 columns x all z per workgroup:  y stage(8) . z . OTF . z^-1 . y stage(8)^-1
+//   xy_kernel        the 64 rows y = n2 + 8m of one z plane per workgroup:  y head^-1 . x^-1 . op . x . y head
+//
+// Both tiles (256 KB / 128 KB) are larger than the LDS, so they live in REGISTERS (64 complex per thread); LDS only
+// carries the exchanges between "all z of one (row, column)" and "all rows of one (z, column)" ownership.  Positions,
+// twiddles and the OTF tiling are exactly those of the classic kernels (same in-place digit-reversed order), so both
+// paths share OTFs and can be mixed stage by stage (MIL_FX_TWOPASS, tests/test_gpu_fft.py).
+#include "fftconv.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace mil {
+namespace fx {
+
+namespace {
+
+#include "fft_dev.h"
+
+constexpr int kNY = 512, kNZ = 256, kNH = 256;  // the box this path is built for: 512 x 512 x 256 (x, y, z)
+constexpr int kPitch = 272;                      // spectrum row pitch (ConvPlan: columns + 16)
+constexpr int kGroups = kNH / kW;                // 16-column groups per row
+
+// Buffer addressing: one 32-bit lane offset + a scalar offset per access, so that the 64 accesses of a register tile
+// share ONE address register instead of 64 pointer pairs.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 x) {
+    u32x2 v;
+    v.x = __float_as_uint(x.x);
+    v.y = __float_as_uint(x.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 x) {
+    u32x4 v;
+    v.x = __float_as_uint(x.x);
+    v.y = __float_as_uint(x.y);
+    v.z = __float_as_uint(x.z);
+    v.w = __float_as_uint(x.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+}
+// Twiddles of the in-register stages: their index is uniform over a wave, and from constant memory that is a scalar
+// load into SGPRs (through a kernel argument the compiler cannot prove the table read-only and fetches every twiddle
+// into a vector register: +40 registers, spills).  Filled by ConvPlan::init_two_pass on the current device.
+__constant__ float2 c_tw_y[kNY];
+__constant__ float2 c_tw_z[kNZ];
+
+constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8;
+constexpr long long kOtfBytes = (long long)kNH * kNY * kNZ * 8;
+constexpr long long kRealBytes = 2LL * kNH * kNY * kNZ * 4;
+
+// ---------------------------------------------------------------------------
+// partial y passes (classic column tiles): head = the stages of length > 8, tail = the stage of length 8
+// ---------------------------------------------------------------------------
+struct PartArgs {
+    float2 *S;
+    const float2 *tw;
+    float2 *col0;  // forward tail: copy of the completed packed column, as the classic forward y pass writes it
+    long long row_stride, outer_stride;
+    int groups;
+};
+
+template <int N, int NT, int PART>
+__global__ __launch_bounds__(NT) void col_part_kernel(PartArgs a) {
+    __shared__ float2 tile[N * kWP];
+    __shared__ float2 tw[N];
+    const int g = blockIdx.x % a.groups;
+    const long long outer = blockIdx.x / a.groups;
+    float2 *base = a.S + outer * a.outer_stride + (long long)g * kW;
+    for (int k = threadIdx.x; k < N; k += NT) tw[k] = a.tw[k];
+    tile_load<N, NT>(tile, base, a.row_stride);
+    lds_barrier();
+    if constexpr (PART == 0) fft_dif<N, N, -1, kW, NT, kWP, 8>(tile, tw);
+    else if constexpr (PART == 1) fft_dit<N, N, +1, kW, NT, 8>(tile, tw);
+    else if constexpr (PART == 2) fft_dif<N, 8, -1, kW, NT, kWP>(tile, tw);
+    else fft_dit<N, 8, +1, kW, NT>(tile, tw);
+    tile_store<N, NT>(tile, base, a.row_stride);
+    if constexpr (PART == 2) {
+        if (g == 0 && a.col0)
+            for (int k = threadIdx.x; k < N; k += NT) a.col0[outer * N + k] = tile[k * kWP];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// yz_conv: y stage(8), z, OTF, z^-1, y stage(8)^-1 on 8 rows x 16 columns x 256 z held in registers
+// ---------------------------------------------------------------------------
+struct YzArgs {
+    float2 *S;
+    const float2 *otf;    // classic tiling [row][g][kz][16]
+    const float2 *otf_q;  // [row][kz]
+    const float2 *tw_z;
+    const unsigned short *neg_y, *neg_z;
+    const unsigned short *pairs;  // [pair][2]: row blocks holding ky and -ky (packed column)
+    int pair_blocks;              // the first blocks do the packed column, one pair of row blocks each (short: they
+                                  // start first so that the long tiles fill in behind them instead of waiting at the end)
+    unsigned long long *stamps;   // timing experiments: 8 wall-clock stamps (100 MHz) per workgroup, or null
+};
+
+#ifdef MIL_FX_STAMPS  // timing experiments: wall-clock stamps at the phase boundaries of one workgroup (tools/twopass_stamps.py)
+#define MIL_STAMP(i)                                                                   \
+    do {                                                                               \
+        if (a.stamps && threadIdx.x == 0) a.stamps[(blockIdx.x % 2048) * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MIL_STAMP(i)
+#endif
+
+constexpr int kYzThreads = 512;
+constexpr int kXchg = 4 * 8 * 16 + 16;  // float2 between consecutive exchanged registers: 4 z-residues x 8 rows x 16 columns (+16: the
+                                         // four register slots a wave reads at once fall on different bank halves)
+
+__global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
+    __shared__ float2 lds[32 * kXchg];  // 135 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float2 *twz = c_tw_z;  // in-register stages; the packed-column path below uses the same table through LDS-style code
+    if ((int)blockIdx.x >= a.pair_blocks) {
+        const int tile_id = blockIdx.x - a.pair_blocks;
+        const int g = tile_id % kGroups, b = tile_id / kGroups;
+        // ownership 1: all z = za + 4m (m = j2 + 8 j1) of one (row j, column)
+        const int col = lane & 15, za = wave & 3, j = (lane >> 4) + 4 * (wave >> 2);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes), ro = make_rsrc(a.otf, kOtfBytes);
+        const unsigned voff = (unsigned)(j * kPitch + col) * 8u;
+        const unsigned soff0 = (unsigned)((za * kNY + 8 * b) * kPitch + g * kW) * 8u;  // + m * zstep
+        constexpr unsigned zstep = 4u * kNY * kPitch * 8u;
+        // ownership 2 (per half h): all 8 rows x 4 z-residues of one (register slot kk, column)
+        const int scol = tid & 15, skk = tid >> 4;  // skk = kb + 8 * (ka - 4h)
+        const unsigned ooff0 = (unsigned)(((8 * b) * kGroups + g) * kNZ * kW) * 8u;
+        const unsigned ovoff = (unsigned)((4 * (skk & 7) + 32 * (skk >> 3)) * kW + scol) * 8u;  // position 4 kb + 32 (ka - 4h)
+        float2 v[64], o[32];
+        auto load_otf = [&](int h) {  // position kc + 4 kb + 32 ka of row jj
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+                    o[kc * 8 + jj] = buf_load2(ro, ovoff, ooff0 + (unsigned)((jj * kGroups * kNZ + 128 * h + kc) * kW) * 8u);
+        };
+        MIL_STAMP(0);
+#pragma unroll
+        for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * zstep);
+        // ---- z forward, stages L = 256 (over j1) and L = 32 (over j2), in registers
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) {
+            float2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
+            dft8<-1>(t);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twz[(za + 4 * j2) * k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
+                }
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) {
+            float2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * ka];
+            dft8<-1>(t);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twz[za * k * 8]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k + 8 * ka] = t[k];
+                }
+        MIL_STAMP(1);
+        load_otf(0);
+        float2 *mine = lds + za * 128 + j * 16 + col;   // + kk * kXchg
+        float2 *slot = lds + skk * kXchg + scol;         // + a * 128 + jj * 16
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) mine[kk * kXchg] = v[32 * h + kk];
+            if (h == 0) MIL_STAMP(8);
+            lds_barrier();
+            if (h == 0) MIL_STAMP(9);
+            float2 u[32];  // [a][jj]
+#pragma unroll
+            for (int q = 0; q < 32; ++q) u[q] = slot[(q >> 3) * 128 + (q & 7) * 16];
+            // y stage of length 8 over the rows, z stage of length 4 over the residues
+#pragma unroll
+            for (int za2 = 0; za2 < 4; ++za2) dft8<-1>(u + 8 * za2);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) dft4<-1>(u[jj], u[8 + jj], u[16 + jj], u[24 + jj]);
+            if (h == 0) MIL_STAMP(10);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) u[q] = c_mul(u[q], o[q]);
+            if (h == 0) MIL_STAMP(11);
+            if (h == 0) load_otf(1);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) dft4<+1>(u[jj], u[8 + jj], u[16 + jj], u[24 + jj]);
+#pragma unroll
+            for (int za2 = 0; za2 < 4; ++za2) dft8<+1>(u + 8 * za2);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) slot[(q >> 3) * 128 + (q & 7) * 16] = u[q];
+            if (h == 0) MIL_STAMP(12);
+            lds_barrier();
+            if (h == 0) MIL_STAMP(13);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) v[32 * h + kk] = mine[kk * kXchg];
+            MIL_STAMP(2 + h);
+        }
+        // ---- z inverse, stages L = 32 and L = 256
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) {
+            float2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * ka];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twz[za * k * 8]);
+            dft8<+1>(t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k + 8 * ka] = t[k];
+                }
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) {
+            float2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twz[(za + 4 * j2) * k]);
+            dft8<+1>(t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
+                }
+        MIL_STAMP(4);
+        if (g != 0 || col != 0) {  // the packed column belongs to the pair blocks below
+#pragma unroll
+            for (int m = 0; m < 64; ++m) buf_store2(rs, voff, soff0 + m * zstep, v[m]);
+        }
+        MIL_STAMP(5);
+#ifdef MIL_FX_STAMPS
+        if (a.stamps) {
+            __builtin_amdgcn_s_waitcnt(0);
+            MIL_STAMP(6);
+        }
+#endif
+        return;
+    }
+    // ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
+    // One workgroup per pair of row blocks, 2 x 8 rows x 256 z of column 0 in LDS as tile[z][17].
+    {
+        float2 *tile = lds;
+        const int pair = blockIdx.x;
+        const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
+        for (int i = tid; i < kNZ * 16; i += kYzThreads) {
+            const int c = i & 15, z = i >> 4;
+            tile[z * kWP + c] = a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch];
+        }
+        lds_barrier();
+        {
+            float2 *p = tile + (tid >> 1) * kWP + 8 * (tid & 1);
+            float2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = p[k];
+            dft8<-1>(t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = t[k];
+        }
+        lds_barrier();
+        fft_dif<kNZ, kNZ, -1, kW, kYzThreads, kWP>(tile, twz);
+        float2 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = i * kYzThreads + tid, c = e & 15, p = e >> 4;
+            const int row = 8 * blk[c >> 3] + (c & 7);
+            const int prow = a.neg_y[row];
+            const int pc = ((prow >> 3) == blk[0] ? 0 : 8) + (prow & 7);
+            const float2 gk = tile[p * kWP + c], gp = tile[a.neg_z[p] * kWP + pc];
+            const float2 pv = a.otf[(((long long)row * kGroups) * kNZ + p) * kW];
+            const float2 qv = a.otf_q[(long long)row * kNZ + p];
+            r[i] = c_add(c_mul(gk, pv), c_mul(qv, make_float2(gp.x, -gp.y)));
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = i * kYzThreads + tid;
+            tile[(e >> 4) * kWP + (e & 15)] = r[i];
+        }
+        lds_barrier();
+        fft_dit<kNZ, kNZ, +1, kW, kYzThreads>(tile, twz);
+        {
+            float2 *p = tile + (tid >> 1) * kWP + 8 * (tid & 1);
+            float2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = p[k];
+            dft8<+1>(t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = t[k];
+        }
+        lds_barrier();
+        const int ncol = (blk[0] == blk[1]) ? 8 : 16;
+        for (int i = tid; i < kNZ * 16; i += kYzThreads) {
+            const int c = i & 15, z = i >> 4;
+            if (c < ncol) a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch] = tile[z * kWP + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// xy pass: the 64 rows y = n2 + 8m of one z plane in registers (thread = column); y head^-1, then per 8 rows
+// x^-1 . op . x through LDS (the classic x kernel's tile), then y head
+// ---------------------------------------------------------------------------
+struct XyArgs {
+    float2 *S;
+    float *E;        // estimate (in / out), update modes
+    const float *M;  // measured image, ratio mode
+    const float2 *tw_x, *tw_y;
+    const unsigned short *pos;
+    float eps;
+    unsigned long long *stamps;  // timing experiments: 8 wall-clock stamps (100 MHz) per workgroup, or null
+};
+
+constexpr int kRawP = kNH;  // float2 per staged spectrum row
+
+// value of the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ float2 swap_pair(float2 a) {
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a.y), 0xB1, 0xF, 0xF, false);
+    return make_float2(__int_as_float(x), __int_as_float(y));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
+    constexpr int RB = 16, WP = RB + 1, NX = 2 * kNH;  // 16 rows per trip through LDS: tile[position][row]
+    __shared__ float2 tile[kNH * WP];
+    __shared__ float2 tw[kNH];       // w_NH^k = w_NX^(2k): the packed complex transform
+    __shared__ float2 twx[kNH / 2];  // w_NX^k: Hermitian fold / split
+    const int tid = threadIdx.x;
+    const int n2 = blockIdx.x & 7, z = blockIdx.x >> 3;
+    const float2 *twy = c_tw_y;
+    tw[tid] = a.tw_x[2 * tid];
+    if (tid < kNH / 2) twx[tid] = a.tw_x[tid];
+    // This thread's spectrum column is X[kc] (even columns) or X[NH - kc] (odd), kc = tid / 2; columns 0 / 1 are the packed
+    // (X[0], X[NH]) and X[NH/2].  The element of the half-length sequence it folds to / splits from sits at position pz.
+    const int kc = tid >> 1;
+    const bool odd = tid & 1;
+    const int pz = a.pos[tid == 1 ? kNH / 2 : (odd ? kNH - kc : kc)];
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, kRealBytes);
+    const unsigned voff = (unsigned)tid * 8u;
+    const unsigned soff0 = (unsigned)((z * kNY + n2) * kPitch) * 8u;  // + m * rstep
+    constexpr unsigned rstep = 8u * kPitch * 8u;
+    // middle stage: this thread owns butterfly i = tid & 31 (elements n = i + 32 j, real x = 2n, 2n + 1) of rows
+    // (tid >> 5) and (tid >> 5) + 8 of the trip; tile row r is volume row y = n2 + 8 r + 128 grp
+    const int bi = tid & 31, br = tid >> 5;
+    const unsigned rvoff = (unsigned)(br * 8 * NX + 2 * bi) * 4u;
+    const unsigned rsoff0 = (unsigned)((z * kNY + n2) * NX) * 4u;  // + grp * 128 rows, + 64 rows for the second item, + 64 j floats
+    constexpr unsigned rgrp = 128u * NX * 4u, ritem = 64u * NX * 4u, rj = 64u * 4u;
+    float2 v[64];
+    float2 pre[16];  // the trip's slice of M / E ([item][j]), requested one trip ahead
+    MIL_STAMP(0);
+#pragma unroll
+    for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * rstep);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff0 + (q >> 3) * ritem + (q & 7) * rj);
+    // ---- y inverse head: DIT stages L = 64 (over j2, m = j2 + 8 j1) and L = 512 (over j1)
+#pragma unroll
+    for (int j1 = 0; j1 < 8; ++j1) {
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * j1];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twy[n2 * k * 8]);
+        dft8<+1>(t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k + 8 * j1] = t[k];
+    }
+#pragma unroll
+    for (int j2 = 0; j2 < 8; ++j2) {
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twy[(n2 + 8 * j2) * k]);
+        dft8<+1>(t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
+    }
+    MIL_STAMP(1);
+    lds_barrier();  // tw, twx
+    const float2 wf = twx[kc];
+    // ---- x^-1 . op . x, sixteen rows per trip (rows m = r + 16 grp).  A real loop: the rows in flight always sit in
+    // v[0..15] and the tile rotates by one group per trip.  (Unrolled, the compiler parks half of the tile in scratch.)
+#pragma unroll 1
+    for (int grp = 0; grp < 64 / RB; ++grp) {
+        const unsigned rsoff = rsoff0 + grp * rgrp;
+        // Hermitian fold, straight from the registers: the lane pair (2k, 2k + 1) holds (X[k], X[NH-k]); each lane forms
+        // its own element of the packed half-length sequence Z' and drops it at that element's digit-reversed position.
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float2 own = v[r], oth = swap_pair(own);
+            float2 x = odd ? oth : own, y = odd ? own : oth;  // x = X[k], y = X[NH-k]
+            if (kc == 0) {  // columns 0 / 1: x = (X[0], X[NH]) packed, y = X[NH/2]
+                y = make_float2(x.y, 0.f);
+                x.y = 0.f;
+            }
+            const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
+            const float ux = wf.x * dx + wf.y * dy, uy = wf.x * dy - wf.y * dx;
+            float2 zf = odd ? make_float2(sx + uy, ux - sy) : make_float2(sx - uy, sy + ux);
+            if (tid == 1) zf = make_float2(2.f * own.x, -2.f * own.y);  // Z'[NH/2] = 2 conj(X[NH/2])
+            tile[pz * WP + r] = zf;
+        }
+        if (grp == 0) MIL_STAMP(8);
+        lds_barrier();
+        if (grp == 0) MIL_STAMP(9);
+        fft_dit<kNH, 32, +1, RB>(tile, tw);  // DIT stages L = 4, 32; the last one (L = 256) is fused below
+        if (grp == 0) MIL_STAMP(10);
+        // ---- last inverse stage, real-space operation, first forward stage on the butterfly's 8 elements
+#pragma unroll
+        for (int item = 0; item < 2; ++item) {
+            float2 *p = tile + bi * WP + br + 8 * item;
+            float2 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[j * 32 * WP];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], tw[bi * k]);
+            dft8<+1>(t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float2 m = pre[item * 8 + j];
+                if (MODE == kXRatio) {  // div3Dkernel: T = A / T (unguarded)
+                    t[j] = make_float2(m.x / t[j].x, m.y / t[j].y);
+                } else {  // multi3Dkernel + maxvalue3Dgpukernel: E = max(E * T, eps)
+                    float2 e = make_float2(m.x * t[j].x, m.y * t[j].y);
+                    e.x = (e.x > a.eps) ? e.x : a.eps;
+                    e.y = (e.y > a.eps) ? e.y : a.eps;
+                    buf_store2(rr, rvoff, rsoff + item * ritem + j * rj, e);
+                    t[j] = e;
+                }
+            }
+            if constexpr (MODE != kXUpdateLast) {
+                dft8<-1>(t);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], tw[bi * k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j * 32 * WP] = t[j];
+            }
+        }
+        if (grp + 1 < 64 / RB) {  // next trip's M / E: in flight during the forward stages and the next fold
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff + rgrp + (q >> 3) * ritem + (q & 7) * rj);
+        }
+        if (grp == 0) MIL_STAMP(11);
+        if constexpr (MODE == kXUpdateLast) {
+#pragma unroll
+            for (int m = 0; m < 64 - RB; ++m) v[m] = v[m + RB];
+            lds_barrier();  // the next fold overwrites the tile
+            continue;
+        }
+        lds_barrier();
+        fft_dif<kNH, 32, -1, RB>(tile, tw);  // DIF stages L = 32, 4
+        if (grp == 0) MIL_STAMP(12);
+        // Hermitian split back into this thread's column: each lane picks up its element Z[k] / Z[NH-k], the pair swaps.
+#pragma unroll
+        for (int m = 0; m < 64 - RB; ++m) v[m] = v[m + RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float2 own = tile[pz * WP + r], oth = swap_pair(own);
+            const float2 x = odd ? oth : own, y = (kc == 0) ? x : (odd ? own : oth);  // x = Z[k], y = Z[NH-k] (k = 0: both Z[0])
+            const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
+            const float tx = wf.x * dx - wf.y * dy, ty = wf.x * dy + wf.y * dx;
+            float2 o = odd ? make_float2(0.5f * (sx - ty), 0.5f * (-sy - tx)) : make_float2(0.5f * (sx + ty), 0.5f * (sy - tx));
+            if (tid == 0) o = make_float2(0.5f * (sx + ty), 0.5f * (sx - ty));  // (X[0], X[NH]), both real
+            if (tid == 1) o = make_float2(own.x, -own.y);                         // X[NH/2] = conj(Z[NH/2])
+            v[64 - RB + r] = o;
+        }
+        if (grp == 0) MIL_STAMP(13);
+        lds_barrier();  // the next fold overwrites the tile
+        if (grp == 0) MIL_STAMP(2);
+    }
+    MIL_STAMP(3);
+    if constexpr (MODE == kXUpdateLast) return;
+    // ---- y forward head: DIF stages L = 512 (over j1) and L = 64 (over j2)
+#pragma unroll
+    for (int j2 = 0; j2 < 8; ++j2) {
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
+        dft8<-1>(t);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twy[(n2 + 8 * j2) * k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
+    }
+#pragma unroll
+    for (int j1 = 0; j1 < 8; ++j1) {
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * j1];
+        dft8<-1>(t);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twy[n2 * k * 8]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k + 8 * j1] = t[k];
+    }
+    MIL_STAMP(4);
+#pragma unroll
+    for (int m = 0; m < 64; ++m) buf_store2(rs, voff, soff0 + m * rstep, v[m]);
+    MIL_STAMP(5);
+#ifdef MIL_FX_STAMPS
+    if (a.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        MIL_STAMP(6);
+    }
+#endif
+}
+
+unsigned long long *g_stamps = nullptr;  // set through mil_fx_set_stamps (timing experiments)
+
+}  // namespace
+
+bool ConvPlan::two_pass_supported(Dims b) { return b.nx == 2 * kNH && b.ny == kNY && b.nz == kNZ; }
+
+void ConvPlan::init_two_pass() {
+    if (!two_pass_supported(box_) || pitch_ != kPitch) return;
+    // pairs of 8-row blocks holding ky and -ky
+    std::vector<unsigned short> fy((size_t)kNY), pos((size_t)kNY), pairs;
+    digit_reversal_freq(kNY, fy.data());
+    for (int q = 0; q < kNY; ++q) pos[fy[(size_t)q]] = (unsigned short)q;
+    for (int b = 0; b < kNY / 8; ++b) {
+        const int nb = pos[(size_t)((kNY - fy[(size_t)(8 * b)]) % kNY)] / 8;
+        for (int j = 0; j < 8; ++j)
+            if (pos[(size_t)((kNY - fy[(size_t)(8 * b + j)]) % kNY)] / 8 != nb) throw Error(-1, "two-pass plan: row blocks do not pair up");
+        if (nb >= b) {
+            pairs.push_back((unsigned short)b);
+            pairs.push_back((unsigned short)nb);
+        }
+    }
+    {
+        std::vector<float2> ty((size_t)kNY), tz((size_t)kNZ);
+        MIL_HIP(hipMemcpy(ty.data(), tw_y_.get(), ty.size() * sizeof(float2), hipMemcpyDeviceToHost));
+        MIL_HIP(hipMemcpy(tz.data(), tw_z_.get(), tz.size() * sizeof(float2), hipMemcpyDeviceToHost));
+        MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_y), ty.data(), ty.size() * sizeof(float2)));
+        MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_z), tz.data(), tz.size() * sizeof(float2)));
+    }
+    n_pairs_ = (int)pairs.size() / 2;
+    pairs_.alloc(pairs.size());
+    MIL_HIP(hipMemcpy(pairs_.get(), pairs.data(), pairs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    two_pass_ = true;
+}
+
+void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
+    if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
+    PartArgs a;
+    a.S = S; a.tw = tw_y_.get(); a.col0 = (part == 2) ? col0_.get() : nullptr;
+    a.row_stride = pitch_; a.outer_stride = (long long)box_.ny * pitch_; a.groups = xs_ / kW;
+    const dim3 grid((unsigned)(a.groups * box_.nz)), block(512);
+    switch (part) {
+        case 0: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 0>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 1>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 2>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 3>), grid, block, 0, s, a); break;
+        default: throw Error(-1, "y_part: unknown part");
+    }
+    MIL_HIP(hipGetLastError());
+}
+
+void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
+    if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
+    YzArgs a;
+    a.S = S; a.otf = otf; a.otf_q = otf + (size_t)xs_ * box_.ny * box_.nz; a.tw_z = tw_z_.get();
+    a.neg_y = neg_y_.get(); a.neg_z = neg_z_.get(); a.pairs = pairs_.get();
+    a.pair_blocks = n_pairs_;
+    a.stamps = g_stamps;
+    hipLaunchKernelGGL(yz_conv_kernel, dim3((unsigned)((kNY / 8) * kGroups + n_pairs_)), dim3(kYzThreads), 0, s, a);
+    MIL_HIP(hipGetLastError());
+}
+
+void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float eps, hipStream_t s) const {
+    if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
+    if (!S || (mode == kXRatio ? !M : !E)) throw Error(-1, "xy_pass: missing operand");
+    XyArgs a;
+    a.S = S; a.E = E; a.M = M; a.tw_x = tw_x_.get(); a.tw_y = tw_y_.get(); a.pos = pos_x_.get(); a.eps = eps;
+    a.stamps = (g_stamps && mode == kXRatio) ? g_stamps + 2048 * 16 : nullptr;
+    const dim3 grid((unsigned)(kNZ * 8)), block(kNT);
+    switch (mode) {
+        case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio>), grid, block, 0, s, a); break;
+        case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate>), grid, block, 0, s, a); break;
+        case kXUpdateLast: hipLaunchKernelGGL((xy_kernel<kXUpdateLast>), grid, block, 0, s, a); break;
+        default: throw Error(-1, "xy_pass: mode must be ratio / update");
+    }
+    MIL_HIP(hipGetLastError());
+}
+
+}  // namespace fx
+}  // namespace mil
+
+// timing experiments (tools/twopass_stamps.py): device buffer of 2 * 2048 * 16 uint64 the two-pass kernels write wall-clock
+// stamps into, or null
+extern "C" int mil_fx_set_stamps(unsigned long long *d_stamps) {
+    mil::fx::g_stamps = d_stamps;
+    return 0;
+}

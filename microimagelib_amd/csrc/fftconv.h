@@ -58,6 +58,19 @@ public:
     // test aid: private OTF order -> natural [nz][ny][nx/2+1] (rocFFT / numpy rfftn order)
     void otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const;
 
+    // ---- two-pass path (csrc/fft2p.hip; 512 x 512 x 256 boxes): the last radix-8 stage of the y transform rides in the
+    // z kernel and its first two in the x kernel, so a half view update is  yz_conv | xy_pass  instead of
+    // y | z_conv | y^-1 | x_pass.  Same spectrum positions and OTFs as the classic kernels.
+    static bool two_pass_supported(Dims box);
+    bool two_pass() const { return two_pass_; }
+    // partial classic y passes: 0 forward head (stages longer than 8), 1 inverse head, 2 forward tail (the stage of
+    // length 8; also refreshes the packed-column copy z_conv reads), 3 inverse tail
+    void y_part(float2 *S, int part, hipStream_t s) const;
+    // S (y head done) <- y tail, z, * otf, z^-1, y tail^-1
+    void yz_conv(float2 *S, const float2 *otf, hipStream_t s) const;
+    // S (y head done) <- y head^-1, x^-1, ratio / update, x, y head     (mode: kXRatio, kXUpdate, kXUpdateLast)
+    void xy_pass(XMode mode, float2 *S, float *E, const float *M, float eps, hipStream_t s) const;
+
 private:
     Dims box_;
     int xs_ = 0;     // spectral columns (multiple of 16)
@@ -68,6 +81,10 @@ private:
     DeviceBuffer<unsigned short> pos_x_;        // position of element n after digit reversal, n in [0, nx/2)
     DeviceBuffer<unsigned short> freq_y_, freq_z_;  // frequency held at scrambled position p
     DeviceBuffer<unsigned short> neg_y_, neg_z_;    // position holding the negated frequency of position p
+    void init_two_pass();
+    bool two_pass_ = false;
+    DeviceBuffer<unsigned short> pairs_;  // two-pass path: pairs of 8-row blocks holding ky and -ky
+    int n_pairs_ = 0;
 };
 
 // Host-side tables (also used by the CPU tests through the C ABI).

@@ -229,6 +229,7 @@ class DeconEngine:
                "mil_decon_create_backend")
         self._h = h
         self.backend = int(self._lib.mil_decon_backend(h))
+        self.two_pass = int(self._lib.mil_decon_two_pass(h))  # fused backend: 3 = two passes per convolution (fft2p.hip)
         self.natural_spectrum_shape = (nz, ny, nx // 2 + 1)
         self.spectrum_count = int(self._lib.mil_decon_spectrum_count(h))  # opaque, backend-private layout
 

@@ -69,3 +69,37 @@ def test_fusion_pipeline_with_independent_registration():
         assert np.array_equal(got[t][1], tmx)
         assert got[t][2][5] == rec[5]  # same number of cost evaluations
         assert np.array_equal(got[t][0], want)
+
+
+def test_overlapped_pipeline_equals_serial():
+    """run_sharded(overlap=True) (read-ahead thread + RL/sink worker) returns the same stack, matrices and records as
+    the serial order, and the sink sees the time points in order."""
+    import torch
+    from microimagelib_amd import batch
+
+    shape = (32, 64, 64)
+    psf_a = do.gaussian_psf((9, 9, 9), (2.0, 1.2, 1.2))
+    psf_b = do.gaussian_psf((9, 9, 9), (1.2, 1.2, 2.0))
+    tps = [1, 2, 3, 4]
+    views = {t: (do.synthetic_view(shape, psf_a, seed=t, noise_seed=10 + t, n_blobs=12),
+                 do.synthetic_view(shape, psf_b, seed=t, noise_seed=20 + t, n_blobs=12)) for t in tps}
+    pol = batch.RegPolicy(reg_mode=3, reg_choice=2, aff_method=1, it_limit=60)
+    runs = {}
+    for overlap in (False, True):
+        pipe = batch.FusionPipeline(shape, torch.from_numpy(psf_a).cuda(), torch.from_numpy(psf_b).cuda(), iters=3)
+        seen = []
+
+        def sink(t, decon, tmx, rec, seen=seen):
+            seen.append((t, decon.cpu().numpy().copy(), tmx.copy(), rec.copy()))
+
+        stack = batch.run_sharded(tps, lambda t: tuple(torch.from_numpy(v).cuda() for v in views[t]), pipe.fuse_pair, pol,
+                                  pipe.reg_fn, pipe.check_fn, (shape[1], shape[2]), sink=sink, device="cuda",
+                                  overlap=overlap)
+        torch.cuda.synchronize()
+        pipe.close()
+        runs[overlap] = (stack.cpu().numpy().copy(), seen)
+    assert [s[0] for s in runs[True][1]] == tps
+    assert np.array_equal(runs[False][0], runs[True][0])
+    for a, b in zip(runs[False][1], runs[True][1]):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3][5] == b[3][5]

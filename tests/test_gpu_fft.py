@@ -125,6 +125,52 @@ def test_backends_agree_at_benchmark_size(dev):
         assert err < 1e-5, ("single" if k == 0 else "dual", err)
 
 
+def test_two_pass_kernels_agree_with_the_classic_sequence(dev, monkeypatch):
+    """csrc/fft2p.hip at 512 x 512 x 256: the yz kernel alone (MIL_FX_TWOPASS=1, partial classic y passes around it), the xy
+    kernel alone (2) and both (3, the default on this box) against the classic four-kernel half update (0) -- 3 single-view
+    and 2 dual-view iterations on the same inputs, the last one through the no-forward-transform form of the x kernel.
+    Same positions, twiddles and OTFs; only the order of the float operations differs."""
+    import torch
+    from tests import fullsize_inputs as fi
+    shape = fi.FULL_SHAPE
+    A, B = T(fi.hash_volume(shape, 1)), T(fi.hash_volume(shape, 2))
+    pa, pb = T(fi.psf_a()), T(fi.psf_b())
+    outs = {}
+    for mode in (0, 1, 2, 3):
+        monkeypatch.setenv("MIL_FX_TWOPASS", str(mode))
+        eng = dev.DeconEngine(shape, backend=dev.DeconEngine.FUSED)
+        assert eng.two_pass == mode
+        oa, ba = eng.gen_otf(pa), eng.gen_otf(pa, flip=True)
+        ob, bb = eng.gen_otf(pb), eng.gen_otf(pb, flip=True)
+        a, b = A.clone(), B.clone()
+        E = torch.empty_like(a)
+        eng.init_single(a, E)
+        eng.run_single(E, a, oa, ba, 3)
+        eng.sync()
+        sv = E.clone()
+        a = A.clone()
+        eng.init_dual(a, b, E)
+        eng.run_dual(E, a, b, oa, ob, ba, bb, 2)
+        eng.sync()
+        outs[mode] = (sv, E.clone())
+        eng.close()
+        del oa, ba, ob, bb
+    monkeypatch.delenv("MIL_FX_TWOPASS")
+    eng = dev.DeconEngine(shape)
+    assert eng.two_pass == 3  # the default where the box allows it
+    eng.close()
+    eng = dev.DeconEngine((64, 128, 128))
+    assert eng.backend == dev.DeconEngine.FUSED and eng.two_pass == 0  # other boxes keep the classic sequence
+    eng.close()
+    for mode in (1, 2, 3):
+        for k in (0, 1):
+            want, got = outs[0][k].double(), outs[mode][k].double()
+            assert bool(torch.isfinite(got).all())
+            floor = float(want.abs().mean())
+            err = float(((got - want).abs() / torch.clamp(want.abs(), min=floor)).max())
+            assert err < 3e-6, (mode, "single" if k == 0 else "dual", err)
+
+
 def test_snap_sized_box_runs_rl_on_the_fused_backend(dev):
     """A 50x180x300 stack snaps to 64x192x320 (radices 3 and 5): fused backend, parity with the oracle."""
     import torch
