@@ -31,7 +31,6 @@ constexpr int kGroups = kNH / kW;                // 16-column groups per row
 // Buffer addressing: one 32-bit lane offset + a scalar offset per access, so that the 64 accesses of a register tile
 // share ONE address register instead of 64 pointer pairs.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
@@ -44,18 +43,6 @@ __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned vo
     v.x = __float_as_uint(x.x);
     v.y = __float_as_uint(x.y);
     __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
-}
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 x) {
-    u32x4 v;
-    v.x = __float_as_uint(x.x);
-    v.y = __float_as_uint(x.y);
-    v.z = __float_as_uint(x.z);
-    v.w = __float_as_uint(x.w);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }
 // Twiddles of the in-register stages: their index is uniform over a wave, and from constant memory that is a scalar
 // load into SGPRs (through a kernel argument the compiler cannot prove the table read-only and fetches every twiddle
@@ -125,10 +112,21 @@ struct YzArgs {
 
 constexpr int kYzThreads = 512;
 constexpr int kXchg = 4 * 8 * 16 + 16;  // float2 between consecutive exchanged registers: 4 z-residues x 8 rows x 16 columns (+16: the
-                                         // four register slots a wave reads at once fall on different bank halves)
+                                         // register slots a wave reads at once fall on different bank halves)
+constexpr int kQuarter = 16;             // registers exchanged at a time (a quarter of the thread's 64)
+constexpr int kPark = 23;                // values of the waiting quarters parked in the rest of the 160 KB
+
+// value of the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ float2 swap_pair(float2 a) {
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a.y), 0xB1, 0xF, 0xF, false);
+    return make_float2(__int_as_float(x), __int_as_float(y));
+}
 
 __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
-    __shared__ float2 lds[32 * kXchg];  // 135 KB
+    // exchange buffer of one quarter (66 KB) + parking space (92 KB): registers are the scarce resource of this kernel,
+    // every spilled one is HBM traffic
+    __shared__ float2 lds[kQuarter * kXchg + kPark * kYzThreads];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float2 *twz = c_tw_z;  // in-register stages; the packed-column path below uses the same table through LDS-style code
@@ -141,21 +139,25 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
         const unsigned voff = (unsigned)(j * kPitch + col) * 8u;
         const unsigned soff0 = (unsigned)((za * kNY + 8 * b) * kPitch + g * kW) * 8u;  // + m * zstep
         constexpr unsigned zstep = 4u * kNY * kPitch * 8u;
-        // ownership 2 (per half h): all 8 rows x 4 z-residues of one (register slot kk, column)
-        const int scol = tid & 15, skk = tid >> 4;  // skk = kb + 8 * (ka - 4h)
-        const unsigned ooff0 = (unsigned)(((8 * b) * kGroups + g) * kNZ * kW) * 8u;
-        const unsigned ovoff = (unsigned)((4 * (skk & 7) + 32 * (skk >> 3)) * kW + scol) * 8u;  // position 4 kb + 32 (ka - 4h)
-        float2 v[64], o[32];
-        auto load_otf = [&](int h) {  // position kc + 4 kb + 32 ka of row jj
+        // ownership 2 (per quarter q: ka = 2q, 2q + 1): a PAIR of lanes shares the 8 rows x 4 z-residues of one (register
+        // slot kk = kb + 8 (ka - 2q), column); lane sp of the pair holds rows sp, sp + 2, sp + 4, sp + 6 going in and the
+        // row frequencies 4 sp .. 4 sp + 3 at the OTF product (the radix-8 row butterfly split over the pair)
+        const int sp = tid & 1, scol = (tid >> 1) & 15, skk = tid >> 5;
+        const unsigned ooff0 = (unsigned)((((8 * b) * kGroups + g) * kNZ) * kW) * 8u;  // wave-uniform part (scalar offset)
+        const unsigned ovoff = (unsigned)((4 * sp * kGroups * kNZ + 4 * (skk & 7) + 32 * (skk >> 3)) * kW + scol) * 8u;  // row 4 sp, position 4 kb + 32 (ka - 2q)
+        float2 v[64], o[2][16];
+        auto load_otf = [&](int q) {  // position kc + 4 kb + 32 ka of row frequency 4 sp + k
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc)
-                    o[kc * 8 + jj] = buf_load2(ro, ovoff, ooff0 + (unsigned)((jj * kGroups * kNZ + 128 * h + kc) * kW) * 8u);
+                    o[q & 1][kc * 4 + k] = buf_load2(ro, ovoff, ooff0 + (unsigned)((k * kGroups * kNZ + 64 * q + kc) * kW) * 8u);
         };
         MIL_STAMP(0);
 #pragma unroll
         for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * zstep);
+        load_otf(0);
+        load_otf(1);
         // ---- z forward, stages L = 256 (over j1) and L = 32 (over j2), in registers
 #pragma unroll
         for (int j2 = 0; j2 < 8; ++j2) {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
             for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twz[(za + 4 * j2) * k]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
-                }
+        }
 #pragma unroll
         for (int ka = 0; ka < 8; ++ka) {
             float2 t[8];
@@ -178,44 +180,95 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
             for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twz[za * k * 8]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k + 8 * ka] = t[k];
-                }
-        MIL_STAMP(1);
-        load_otf(0);
-        float2 *mine = lds + za * 128 + j * 16 + col;   // + kk * kXchg
-        float2 *slot = lds + skk * kXchg + scol;         // + a * 128 + jj * 16
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk) mine[kk * kXchg] = v[32 * h + kk];
-            if (h == 0) MIL_STAMP(8);
-            lds_barrier();
-            if (h == 0) MIL_STAMP(9);
-            float2 u[32];  // [a][jj]
-#pragma unroll
-            for (int q = 0; q < 32; ++q) u[q] = slot[(q >> 3) * 128 + (q & 7) * 16];
-            // y stage of length 8 over the rows, z stage of length 4 over the residues
-#pragma unroll
-            for (int za2 = 0; za2 < 4; ++za2) dft8<-1>(u + 8 * za2);
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) dft4<-1>(u[jj], u[8 + jj], u[16 + jj], u[24 + jj]);
-            if (h == 0) MIL_STAMP(10);
-#pragma unroll
-            for (int q = 0; q < 32; ++q) u[q] = c_mul(u[q], o[q]);
-            if (h == 0) MIL_STAMP(11);
-            if (h == 0) load_otf(1);
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) dft4<+1>(u[jj], u[8 + jj], u[16 + jj], u[24 + jj]);
-#pragma unroll
-            for (int za2 = 0; za2 < 4; ++za2) dft8<+1>(u + 8 * za2);
-#pragma unroll
-            for (int q = 0; q < 32; ++q) slot[(q >> 3) * 128 + (q & 7) * 16] = u[q];
-            if (h == 0) MIL_STAMP(12);
-            lds_barrier();
-            if (h == 0) MIL_STAMP(13);
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk) v[32 * h + kk] = mine[kk * kXchg];
-            MIL_STAMP(2 + h);
         }
+        MIL_STAMP(1);
+        float2 *mine = lds + za * 128 + j * 16 + col;                  // + kk * kXchg
+        float2 *slot = lds + skk * kXchg + sp * 16 + scol;              // + a * 128 + i * 32   (row sp + 2 i)
+        float2 *park = lds + kQuarter * kXchg + tid;                   // + i * kYzThreads, this thread's own slots
+        // Parking plan (values by register index): v[32..54] wait in LDS from the start; when quarter 2 / 3 picks its inputs
+        // up, the results of quarter 0 / 1 take the freed places; everything comes back after the last quarter.
+#pragma unroll
+        for (int i = 0; i < kPark; ++i) park[i * kYzThreads] = v[32 + i];
+        constexpr float h8 = 0.70710678118654752440f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v[32 + i] = park[i * kYzThreads];
+                    park[i * kYzThreads] = v[i];  // results of quarter 0
+                }
+            }
+            if (q == 3) {
+#pragma unroll
+                for (int i = 16; i < kPark; ++i) {
+                    v[32 + i] = park[i * kYzThreads];
+                    park[i * kYzThreads] = v[i];  // 7 results of quarter 1
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) mine[kk * kXchg] = v[16 * q + kk];
+            if (q == 0) MIL_STAMP(8);
+            lds_barrier();
+            if (q == 0) MIL_STAMP(9);
+            float2 u[16];  // [a][i]: z-residue a, row sp + 2 i
+#pragma unroll
+            for (int e = 0; e < 16; ++e) u[e] = slot[(e >> 2) * 128 + (e & 3) * 32];
+            // y stage of length 8 over the rows, split over the lane pair (decimation in time): each lane transforms its four
+            // rows, the odd lane applies w8^k, then  row k = even + odd,  row k + 4 = even - odd
+#pragma unroll
+            for (int za2 = 0; za2 < 4; ++za2) {
+                float2 *w = u + 4 * za2;
+                dft4<-1>(w[0], w[1], w[2], w[3]);
+                if (sp) {
+                    w[1] = c_add(w[1], rot90<-1>(w[1])) * make_float2(h8, h8);
+                    w[2] = rot90<-1>(w[2]);
+                    w[3] = c_sub(rot90<-1>(w[3]), w[3]) * make_float2(h8, h8);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float2 oth = swap_pair(w[k]);
+                    w[k] = sp ? c_sub(oth, w[k]) : c_add(w[k], oth);
+                }
+            }
+            // z stage of length 4 over the residues
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dft4<-1>(u[k], u[4 + k], u[8 + k], u[12 + k]);
+            if (q == 0) MIL_STAMP(10);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) u[e] = c_mul(u[e], o[q & 1][e]);
+            if (q == 0) MIL_STAMP(11);
+            if (q + 2 < 4) load_otf(q + 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dft4<+1>(u[k], u[4 + k], u[8 + k], u[12 + k]);
+            // y stage back (decimation in frequency): s = x_r + x_(r+4) on the even lane, d = (x_r - x_(r+4)) w8^-r on the odd
+            // one, then each lane transforms its four: even lane -> rows 0, 2, 4, 6, odd lane -> rows 1, 3, 5, 7
+#pragma unroll
+            for (int za2 = 0; za2 < 4; ++za2) {
+                float2 *w = u + 4 * za2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float2 oth = swap_pair(w[k]);
+                    w[k] = sp ? c_sub(oth, w[k]) : c_add(w[k], oth);
+                }
+                if (sp) {
+                    w[1] = c_add(w[1], rot90<+1>(w[1])) * make_float2(h8, h8);
+                    w[2] = rot90<+1>(w[2]);
+                    w[3] = c_sub(rot90<+1>(w[3]), w[3]) * make_float2(h8, h8);
+                }
+                dft4<+1>(w[0], w[1], w[2], w[3]);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slot[(e >> 2) * 128 + (e & 3) * 32] = u[e];
+            if (q == 0) MIL_STAMP(12);
+            lds_barrier();
+            if (q == 0) MIL_STAMP(13);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) v[16 * q + kk] = mine[kk * kXchg];
+            if (q < 2) MIL_STAMP(2 + q);
+        }
+#pragma unroll
+        for (int i = 0; i < kPark; ++i) v[i] = park[i * kYzThreads];
         // ---- z inverse, stages L = 32 and L = 256
 #pragma unroll
         for (int ka = 0; ka < 8; ++ka) {
@@ -327,14 +380,6 @@ struct XyArgs {
     unsigned long long *stamps;  // timing experiments: 8 wall-clock stamps (100 MHz) per workgroup, or null
 };
 
-constexpr int kRawP = kNH;  // float2 per staged spectrum row
-
-// value of the neighbouring lane (lane ^ 1)
-__device__ __forceinline__ float2 swap_pair(float2 a) {
-    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
-    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a.y), 0xB1, 0xF, 0xF, false);
-    return make_float2(__int_as_float(x), __int_as_float(y));
-}
 
 template <int MODE>
 __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
