@@ -396,25 +396,27 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     // (X[0], X[NH]) and X[NH/2].  The element of the half-length sequence it folds to / splits from sits at position pz.
     const int kc = tid >> 1;
     const bool odd = tid & 1;
-    const int pz = a.pos[tid == 1 ? kNH / 2 : (odd ? kNH - kc : kc)];
+    // (the x transform of this kernel is 16 x 16: element k = a + 16 b of the half-length sequence sits at position 16 a + b)
+    const int ez = tid == 1 ? kNH / 2 : (odd ? kNH - kc : kc);
+    const int pz = 16 * (ez & 15) + (ez >> 4);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, kRealBytes);
     const unsigned voff = (unsigned)tid * 8u;
     const unsigned soff0 = (unsigned)((z * kNY + n2) * kPitch) * 8u;  // + m * rstep
     constexpr unsigned rstep = 8u * kPitch * 8u;
-    // middle stage: this thread owns butterfly i = tid & 31 (elements n = i + 32 j, real x = 2n, 2n + 1) of rows
-    // (tid >> 5) and (tid >> 5) + 8 of the trip; tile row r is volume row y = n2 + 8 r + 128 grp
-    const int bi = tid & 31, br = tid >> 5;
+    // middle stage: this thread owns butterfly i = tid & 15 (elements n = i + 16 j, real x = 2n, 2n + 1) of row tid >> 4 of
+    // the trip; tile row r is volume row y = n2 + 8 r + 128 grp
+    const int bi = tid & 15, br = tid >> 4;
     const unsigned rvoff = (unsigned)(br * 8 * NX + 2 * bi) * 4u;
-    const unsigned rsoff0 = (unsigned)((z * kNY + n2) * NX) * 4u;  // + grp * 128 rows, + 64 rows for the second item, + 64 j floats
-    constexpr unsigned rgrp = 128u * NX * 4u, ritem = 64u * NX * 4u, rj = 64u * 4u;
+    const unsigned rsoff0 = (unsigned)((z * kNY + n2) * NX) * 4u;  // + grp * 128 rows, + 32 j floats
+    constexpr unsigned rgrp = 128u * NX * 4u, rj = 32u * 4u;
     float2 v[64];
-    float2 pre[16];  // the trip's slice of M / E ([item][j]), requested one trip ahead
+    float2 pre[16];  // the trip's slice of M / E (element j of the butterfly), requested one trip ahead
     MIL_STAMP(0);
 #pragma unroll
     for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * rstep);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff0 + (q >> 3) * ritem + (q & 7) * rj);
+    for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff0 + q * rj);
     // ---- y inverse head: DIT stages L = 64 (over j2, m = j2 + 8 j1) and L = 512 (over j1)
 #pragma unroll
     for (int j1 = 0; j1 < 8; ++j1) {
@@ -465,42 +467,42 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
         if (grp == 0) MIL_STAMP(8);
         lds_barrier();
         if (grp == 0) MIL_STAMP(9);
-        fft_dit<kNH, 32, +1, RB>(tile, tw);  // DIT stages L = 4, 32; the last one (L = 256) is fused below
+        fft_stage<kNH, 16, 16, true, +1, RB>(tile, tw);  // DIT stage L = 16; the other one (L = 256) is fused below
+        lds_barrier();
         if (grp == 0) MIL_STAMP(10);
-        // ---- last inverse stage, real-space operation, first forward stage on the butterfly's 8 elements
+        // ---- last inverse stage, real-space operation, first forward stage on the butterfly's 16 elements
+        {
+            float2 *p = tile + bi * WP + br;
+            float2 t[16];
 #pragma unroll
-        for (int item = 0; item < 2; ++item) {
-            float2 *p = tile + bi * WP + br + 8 * item;
-            float2 t[8];
+            for (int j = 0; j < 16; ++j) t[j] = p[j * 16 * WP];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = p[j * 32 * WP];
+            for (int k = 1; k < 16; ++k) t[k] = tw_mul<+1>(t[k], tw[bi * k]);
+            dft16<+1>(t);
 #pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], tw[bi * k]);
-            dft8<+1>(t);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float2 m = pre[item * 8 + j];
+            for (int j = 0; j < 16; ++j) {
+                const float2 m = pre[j];
                 if (MODE == kXRatio) {  // div3Dkernel: T = A / T (unguarded)
                     t[j] = make_float2(m.x / t[j].x, m.y / t[j].y);
                 } else {  // multi3Dkernel + maxvalue3Dgpukernel: E = max(E * T, eps)
                     float2 e = make_float2(m.x * t[j].x, m.y * t[j].y);
                     e.x = (e.x > a.eps) ? e.x : a.eps;
                     e.y = (e.y > a.eps) ? e.y : a.eps;
-                    buf_store2(rr, rvoff, rsoff + item * ritem + j * rj, e);
+                    buf_store2(rr, rvoff, rsoff + j * rj, e);
                     t[j] = e;
                 }
             }
             if constexpr (MODE != kXUpdateLast) {
-                dft8<-1>(t);
+                dft16<-1>(t);
 #pragma unroll
-                for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], tw[bi * k]);
+                for (int k = 1; k < 16; ++k) t[k] = tw_mul<-1>(t[k], tw[bi * k]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) p[j * 32 * WP] = t[j];
+                for (int j = 0; j < 16; ++j) p[j * 16 * WP] = t[j];
             }
         }
         if (grp + 1 < 64 / RB) {  // next trip's M / E: in flight during the forward stages and the next fold
 #pragma unroll
-            for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff + rgrp + (q >> 3) * ritem + (q & 7) * rj);
+            for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff + rgrp + q * rj);
         }
         if (grp == 0) MIL_STAMP(11);
         if constexpr (MODE == kXUpdateLast) {
@@ -510,7 +512,8 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
             continue;
         }
         lds_barrier();
-        fft_dif<kNH, 32, -1, RB>(tile, tw);  // DIF stages L = 32, 4
+        fft_stage<kNH, 16, 16, false, -1, RB>(tile, tw);  // DIF stage L = 16
+        lds_barrier();
         if (grp == 0) MIL_STAMP(12);
         // Hermitian split back into this thread's column: each lane picks up its element Z[k] / Z[NH-k], the pair swaps.
 #pragma unroll

@@ -72,6 +72,48 @@ __device__ __forceinline__ void dft8(float2 *v) {
     v[7] = c_sub(e3, o3);
 }
 
+// a * w16^M, w16 = exp(SIGN * 2 pi i / 16), M known at compile time
+template <int SIGN, int M>
+__device__ __forceinline__ float2 mul_w16(float2 a) {
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    if constexpr (M == 0) return a;
+    else if constexpr (M == 4) return rot90<SIGN>(a);
+    else if constexpr (M == 2) return c_add(a, rot90<SIGN>(a)) * make_float2(h, h);
+    else if constexpr (M == 6) return c_sub(rot90<SIGN>(a), a) * make_float2(h, h);
+    else {  // a * (cos t + SIGN i sin t) = a cos t + rot90(a) sin t
+        static_assert(M == 1 || M == 3 || M == 9, "mul_w16: exponent not used by dft16");
+        constexpr float c = (M == 1) ? c1 : (M == 3) ? s1 : -c1;
+        constexpr float s = (M == 1) ? s1 : (M == 3) ? c1 : -s1;
+        return a * make_float2(c, c) + rot90<SIGN>(a) * make_float2(s, s);
+    }
+}
+
+// 16-point transform, natural order in and out: n = 4 n1 + n2, k = k1 + 4 k2 (4 x 4 with the w16 twiddles in between)
+template <int SIGN>
+__device__ __forceinline__ void dft16(float2 *v) {
+    dft4<SIGN>(v[0], v[4], v[8], v[12]);  // over n1 for n2 = 0: y[n2][k1] lands in v[n2 + 4 k1]
+    dft4<SIGN>(v[1], v[5], v[9], v[13]);
+    dft4<SIGN>(v[2], v[6], v[10], v[14]);
+    dft4<SIGN>(v[3], v[7], v[11], v[15]);
+    v[5] = mul_w16<SIGN, 1>(v[5]);
+    v[9] = mul_w16<SIGN, 2>(v[9]);
+    v[13] = mul_w16<SIGN, 3>(v[13]);
+    v[6] = mul_w16<SIGN, 2>(v[6]);
+    v[10] = mul_w16<SIGN, 4>(v[10]);
+    v[14] = mul_w16<SIGN, 6>(v[14]);
+    v[7] = mul_w16<SIGN, 3>(v[7]);
+    v[11] = mul_w16<SIGN, 6>(v[11]);
+    v[15] = mul_w16<SIGN, 9>(v[15]);
+    dft4<SIGN>(v[0], v[1], v[2], v[3]);  // over n2 for k1 = 0: X[k1 + 4 k2] lands in v[k2 + 4 k1]
+    dft4<SIGN>(v[4], v[5], v[6], v[7]);
+    dft4<SIGN>(v[8], v[9], v[10], v[11]);
+    dft4<SIGN>(v[12], v[13], v[14], v[15]);
+    float2 t;  // transpose to natural order
+#define MIL_SWAP16(a, b) t = v[a]; v[a] = v[b]; v[b] = t;
+    MIL_SWAP16(1, 4) MIL_SWAP16(2, 8) MIL_SWAP16(3, 12) MIL_SWAP16(6, 9) MIL_SWAP16(7, 13) MIL_SWAP16(11, 14)
+#undef MIL_SWAP16
+}
+
 // cos / sin(2*pi*k/R) for the odd radices
 template <int R>
 struct OddTable;
@@ -136,7 +178,8 @@ __device__ __forceinline__ void dft_odd(float2 *v) {
 
 template <int R, int SIGN>
 __device__ __forceinline__ void dft_small(float2 *v) {
-    if constexpr (R == 8) dft8<SIGN>(v);
+    if constexpr (R == 16) dft16<SIGN>(v);
+    else if constexpr (R == 8) dft8<SIGN>(v);
     else if constexpr (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
     else if constexpr (R == 2) dft2<SIGN>(v);
     else dft_odd<R, SIGN>(v);
