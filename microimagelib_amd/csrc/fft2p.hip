@@ -93,7 +93,6 @@ struct YzArgs {
     float2 *S;
     const float2 *otf;    // classic tiling [row][g][kz][16]
     const float2 *otf_q;  // [row][kz]
-    const float2 *tw_z;
     const unsigned short *neg_y, *neg_z;
     const unsigned short *pairs;  // [pair][2]: row blocks holding ky and -ky (packed column)
     int pair_blocks;              // the first blocks do the packed column, one pair of row blocks each (short: they
@@ -374,8 +373,7 @@ struct XyArgs {
     float2 *S;
     float *E;        // estimate (in / out), update modes
     const float *M;  // measured image, ratio mode
-    const float2 *tw_x, *tw_y;
-    const unsigned short *pos;
+    const float2 *tw_x;
     float eps;
     unsigned long long *stamps;  // timing experiments: 8 wall-clock stamps (100 MHz) per workgroup, or null
 };
@@ -623,7 +621,7 @@ void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
 void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
     YzArgs a;
-    a.S = S; a.otf = otf; a.otf_q = otf + (size_t)xs_ * box_.ny * box_.nz; a.tw_z = tw_z_.get();
+    a.S = S; a.otf = otf; a.otf_q = otf + (size_t)xs_ * box_.ny * box_.nz;
     a.neg_y = neg_y_.get(); a.neg_z = neg_z_.get(); a.pairs = pairs_.get();
     a.pair_blocks = n_pairs_;
     a.stamps = g_stamps;
@@ -635,7 +633,7 @@ void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float ep
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
     if (!S || (mode == kXRatio ? !M : !E)) throw Error(-1, "xy_pass: missing operand");
     XyArgs a;
-    a.S = S; a.E = E; a.M = M; a.tw_x = tw_x_.get(); a.tw_y = tw_y_.get(); a.pos = pos_x_.get(); a.eps = eps;
+    a.S = S; a.E = E; a.M = M; a.tw_x = tw_x_.get(); a.eps = eps;
     a.stamps = (g_stamps && mode == kXRatio) ? g_stamps + 2048 * 16 : nullptr;
     const dim3 grid((unsigned)(kNZ * 8)), block(kNT);
     switch (mode) {
