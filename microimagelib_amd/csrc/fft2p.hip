@@ -382,7 +382,9 @@ struct XyArgs {
 template <int MODE>
 __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     constexpr int RB = 16, WP = RB + 1, NX = 2 * kNH;  // 16 rows per trip through LDS: tile[position][row]
-    __shared__ float2 tile[kNH * WP];
+    // position p of the half-length sequence, row r: tile[p * WP + (p >> 4) + r] -- the skew keeps the fold / split, which
+    // step through the positions 16 at a time, from hammering two banks (54 % of the LDS cycles were conflicts without it)
+    __shared__ float2 tile[kNH * WP + 16];
     __shared__ float2 tw[kNH];       // w_NH^k = w_NX^(2k): the packed complex transform
     __shared__ float2 twx[kNH / 2];  // w_NX^k: Hermitian fold / split
     const int tid = threadIdx.x;
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     // (the x transform of this kernel is 16 x 16: element k = a + 16 b of the half-length sequence sits at position 16 a + b)
     const int ez = tid == 1 ? kNH / 2 : (odd ? kNH - kc : kc);
     const int pz = 16 * (ez & 15) + (ez >> 4);
+    const int pzs = pz * WP + (pz >> 4);  // its place in the skewed tile
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, kRealBytes);
     const unsigned voff = (unsigned)tid * 8u;
@@ -460,12 +463,12 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
             const float ux = wf.x * dx + wf.y * dy, uy = wf.x * dy - wf.y * dx;
             float2 zf = odd ? make_float2(sx + uy, ux - sy) : make_float2(sx - uy, sy + ux);
             if (tid == 1) zf = make_float2(2.f * own.x, -2.f * own.y);  // Z'[NH/2] = 2 conj(X[NH/2])
-            tile[pz * WP + r] = zf;
+            tile[pzs + r] = zf;
         }
         if (grp == 0) MIL_STAMP(8);
         lds_barrier();
         if (grp == 0) MIL_STAMP(9);
-        fft_stage<kNH, 16, 16, true, +1, RB>(tile, tw);  // DIT stage L = 16; the other one (L = 256) is fused below
+        fft_stage<kNH, 16, 16, true, +1, RB, kNT, RB + 1, true>(tile, tw);  // DIT stage L = 16; the other one (L = 256) is fused below
         lds_barrier();
         if (grp == 0) MIL_STAMP(10);
         // ---- last inverse stage, real-space operation, first forward stage on the butterfly's 16 elements
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
             float2 *p = tile + bi * WP + br;
             float2 t[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) t[j] = p[j * 16 * WP];
+            for (int j = 0; j < 16; ++j) t[j] = p[j * (16 * WP + 1)];
 #pragma unroll
             for (int k = 1; k < 16; ++k) t[k] = tw_mul<+1>(t[k], tw[bi * k]);
             dft16<+1>(t);
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
 #pragma unroll
                 for (int k = 1; k < 16; ++k) t[k] = tw_mul<-1>(t[k], tw[bi * k]);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) p[j * 16 * WP] = t[j];
+                for (int j = 0; j < 16; ++j) p[j * (16 * WP + 1)] = t[j];
             }
         }
         if (grp + 1 < 64 / RB) {  // next trip's M / E: in flight during the forward stages and the next fold
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
             continue;
         }
         lds_barrier();
-        fft_stage<kNH, 16, 16, false, -1, RB>(tile, tw);  // DIF stage L = 16
+        fft_stage<kNH, 16, 16, false, -1, RB, kNT, RB + 1, true>(tile, tw);  // DIF stage L = 16
         lds_barrier();
         if (grp == 0) MIL_STAMP(12);
         // Hermitian split back into this thread's column: each lane picks up its element Z[k] / Z[NH-k], the pair swaps.
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
         for (int m = 0; m < 64 - RB; ++m) v[m] = v[m + RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const float2 own = tile[pz * WP + r], oth = swap_pair(own);
+            const float2 own = tile[pzs + r], oth = swap_pair(own);
             const float2 x = odd ? oth : own, y = (kc == 0) ? x : (odd ? own : oth);  // x = Z[k], y = Z[NH-k] (k = 0: both Z[0])
             const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
             const float tx = wf.x * dx - wf.y * dy, ty = wf.x * dy + wf.y * dx;
