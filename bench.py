@@ -66,6 +66,17 @@ def gaussian_psf(shape, sigma_zyx):
     return (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
 
 
+def kernel_source_hashes():
+    """sha256 of the kernel sources the PMC traffic figures depend on (profiles/pmc_traffic.json carries the same map)."""
+    import hashlib
+    out = {}
+    for f in ("fft.hip", "fft2p.hip", "fft_dev.h", "kernels.hip"):
+        path = os.path.join(ROOT, "microimagelib_amd", "csrc", f)
+        if os.path.exists(path):
+            out[f] = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    return out
+
+
 def cpu_baseline(img_host, psf_host, iters, threads):
     """The library's own gpuMemMode 0 path -- the C++ restatement of the reference's CPU twin (decon_singleview_OTF0,
     src/api_subfunc.cu:3310-3359: same order of operations, separate element-wise passes, bundled mixed-radix FFT in
@@ -103,7 +114,7 @@ def main():
                     help="time points per GPU of the config-5 figure in `extra` (register + joint RL + MIP); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=4, help="RL iterations of the single-thread CPU baseline (~3 s each)")
+    ap.add_argument("--cpu-iters", type=int, default=10, help="RL iterations of the single-thread CPU baseline (~1 s each)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="second CPU figure on this many threads (a 1-GPU box's share of host cores); 1 = skip")
     # functional test of the N > 1 path on a one-GPU box: all ranks on cuda:0, collectives over gloo (never a measurement)
@@ -253,11 +264,21 @@ def main():
         dom_bytes = fam[dom][2]
         dom_avg_ms = dom_ms / max(dom_n, 1)  # measured inside the timed region
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_n else None
-        traffic = None
+        # HBM bytes per launch from the PMC counters: a separate rocprofv3 run (tools/gpu_profile_run.sh) recorded in
+        # profiles/pmc_traffic.json together with the hashes of the kernel sources it was measured on.  A kernel edited
+        # since then invalidates the number: traffic is then null, not a stale constant.
+        traffic, traffic_meta = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("fused" if fused else "rocfft", {}).get(dom.split(" ")[0])
+                tj = json.load(open(tfile))
+                want = tj.get("sources_sha256", {})
+                now = kernel_source_hashes()
+                stale = [f for f, h in want.items() if now.get(f) != h]
+                traffic_meta = {"measured_on_commit": tj.get("commit"), "kernel_symbol": tj.get("symbols", {}).get(dom.split(" ")[0]),
+                                "stale_sources": stale}
+                if want and not stale:
+                    traffic = tj.get("fused" if fused else "rocfft", {}).get(dom.split(" ")[0])
             except Exception:
                 traffic = None
         result = {
@@ -290,6 +311,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                 "traffic": traffic,
+                "traffic_provenance": traffic_meta,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_ms": round(dom_avg_ms, 5),
                 "launches": int(dom_n),
@@ -307,7 +329,11 @@ def main():
                 "iteration_algorithmic_bytes": 4 * (R + C) + 2 * 3 * C + 3 * R + 3 * R,
                 "iteration_hbm_roofline_frac": round((4 * (R + C) + 6 * C + 6 * R) / (elapsed / args.steps) / 1e9
                                                      / HBM_PEAK_GBS, 4),
+                "iteration_hbm_roofline_frac_note": "work-equivalent: SURVEY 8(d)'s bytes of the ideal per-stage-fused "
+                                                    "iteration over this backend's time -- NOT the bytes this backend moves",
                 "iteration_bytes_this_backend_minimum": iter_bytes,
+                # what the kernels of this backend really have to move, over the same time: the achieved HBM fraction
+                "iteration_hbm_achieved_frac": round(iter_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "mip_checksum": mip_checksum,
                 # north_star: ">= 60 % of HBM-read roofline on the RL element-wise update" -- the kernel that carries it
                 # (fused backend: x^-1 . E = max(E*T, eps) . x on 2C + 2R bytes; rocFFT backend: the 3R update kernel)
@@ -367,6 +393,15 @@ def main():
         eng.sync()
         dual_s = time.perf_counter() - t0
         result["extra"]["dualview_iterations_per_s"] = round(args.steps / dual_s, 3)
+        dual_bytes = 2 * result["extra"]["iteration_bytes_this_backend_minimum"]  # two view updates per iteration
+        result["extra"]["dualview"] = {
+            "workload": "deconDualView joint RL (2 PSFs) 512x512x256 (BASELINE.json configs[2])",
+            "iterations_per_s": round(args.steps / dual_s, 3), "ms_per_iteration": round(1e3 * dual_s / args.steps, 4),
+            "roofline": {"bound": "hbm", "bytes_per_iteration_this_backend": dual_bytes,
+                         "achieved": round(dual_bytes / (dual_s / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(dual_bytes / (dual_s / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "work_equivalent_frac": round(2 * result["extra"]["iteration_algorithmic_bytes"]
+                                                       / (dual_s / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}}
         del B, img_b, otf_b, bp_b
 
         # registration: source = target warped by a known matrix (rotation 3 deg about y, scale 1.02, shift)
@@ -391,6 +426,13 @@ def main():
             "zncc_initial": round(float(rec[1]), 5),
             "zncc_final": round(float(rec[3]), 5),
             "hbm_roofline_frac_per_eval": round(2 * R * launches / opt_s / 1e9 / HBM_PEAK_GBS, 4) if opt_s > 0 else None,
+            # per launched evaluation: read target once + source once (2R = 536 870 912 B), whole optimisation
+            # time (kernel + launch + poll + Powell's host logic) in the denominator
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_evaluation": 2 * R,
+                         "achieved": round(2 * R * launches / opt_s / 1e9, 1) if opt_s > 0 else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s",
+                         "frac": round(2 * R * launches / opt_s / 1e9 / HBM_PEAK_GBS, 4) if opt_s > 0 else None,
+                         "us_per_launched_evaluation": round(1e6 * opt_s / launches, 2) if launches else None},
         }
         # the same pair through the direct 12-DOF search (affMethod 5), SURVEY.md section 8(d)
         reg5, tmx5, rec5 = mdev.reg3d_affine(target, source, aff_method=5, ftol=1e-4, it_limit=3000)

@@ -14,10 +14,15 @@
  *   - the library allocates and frees every device buffer inside the call.
  *
  * Differences from the reference, all deliberate:
- *   - gpuMemMode 0 (the FFTW CPU path) is not provided: the call returns non-zero
- *     and prints a message, as the reference itself does for CPU registration
+ *   - gpuMemMode 0 of the deconvolution entry points is a host implementation of the reference's
+ *     decon_*_OTF0 (src/api_subfunc.cu:3310-3359, 3519-3585) with a bundled FFT in place of FFTW
+ *     and the GPU path's PSF placement (csrc/cpu_decon.cpp); auto mode (-1) falls to it only when
+ *     the volume does not fit the device.  CPU registration stays unsupported, as upstream
  *     (src/api_reg.cpp:390-393).  gpuMemMode 2 is executed as mode 1 (288 GB HBM).
  *   - timings in the records arrays are wall-clock seconds, not clock() CPU time.
+ *   - deconRecords[7], which the reference never writes, holds the preparation time (see below).
+ *   - every entry point may be called from several host threads at once, on the same or on
+ *     different devices (deviceNum); calls on different devices do not serialise.
  */
 #ifndef MICROIMAGELIB_AMD_LIBAPI_H
 #define MICROIMAGELIB_AMD_LIBAPI_H
@@ -73,9 +78,13 @@ int reg2d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int 
 /* ------------------------------------------------------------------ 3-D deconvolution
  * reference: include/libapi.h:42-46, src/api_decon.cpp:53-331, 333-704
  *   initialFlag   true: constant initial estimate (the reference uses the SUM of the image)
- *   gpuMemMode    -1 auto | 1 | 2 (run as 1) | 0 unsupported here
- *   deconRecords[10]: [0] mode used, [1..5] free MB snapshots, [6] init s, [7] unused,
- *                     [8] decon s, [9] total s
+ *   gpuMemMode    -1 auto (1, or 0 when the volume does not fit the device) | 1 | 2 (run as 1) |
+ *                 0 host path (no device call at all)
+ *   deconRecords[10]: [0] mode used, [1..5] free MB snapshots (0 in mode 0), [6] init s,
+ *                     [7] preparation s: OTFs + upload + initial estimate (GPU modes) / OTF
+ *                     generation (mode 0) -- the reference leaves [7] unset (src/api_decon.cpp:
+ *                     300-312), so a caller written against it never reads this slot,
+ *                     [8] decon s (the RL loop), [9] total s
  *   flagUnmatch   true: h_psf_bp* are explicit back projectors; false: flipped PSF
  * returns 0 ok; 1 (single) / -1 (dual) on a bad gpuMemMode, like the reference. */
 int decon_singleview(float *h_decon, float *h_img, unsigned int *imSize, float *h_psf, unsigned int *psfSize,

@@ -24,15 +24,18 @@ extern "C" {
 const char *mil_version(void);
 int mil_device_count(void);
 int mil_set_device(int device);               /* cudaSetDevice(deviceNum), src/api_decon.cpp:102 */
-int mil_snap_transform_size(int n);
+int mil_snap_transform_size(int n);            /* snapTransformSize, src/api_subfunc.cu:57-87 */
 /* Interpolation weights of every resample / cost kernel: 0 = exact float32 (default), 8 = rounded to 8 fractional bits,
  * emulating the CUDA texture unit the reference samples through (include/cukernel.cuh:510-522, 545-546; rounding to nearest
  * is an assumption, the CUDA guide documents only the format).  A comparison aid for data produced by the CUDA build;
  * process-wide; any other value returns control to MIL_TEX_WEIGHT_BITS.  Returns the setting in force. */
 int mil_set_texture_weight_bits(int bits);
 /* Device buffers freed inside the library are kept for the next call of the same size (the reference re-allocates ~2 GB per
- * libapi.h call); this returns them to the driver.  Returns the number of bytes released.  MIL_POOL_MB caps the cache. */
-size_t mil_release_cached_memory(void);           /* snapTransformSize, src/api_subfunc.cu:57-87 */
+ * libapi.h call), and decon_singleview / decon_dualview keep their engine + OTFs per (device, FFT box); this returns all of
+ * it to the driver (entries a concurrent call is using are left alone).  Returns the number of pool bytes released.
+ * MIL_POOL_MB caps the pool per device (default min(6144 MB, 1/16 of the device), least recently freed blocks go first). */
+size_t mil_release_cached_memory(void);
+size_t mil_cached_memory_bytes(void);             /* bytes the pool holds right now (all devices) */
 
 /* ---- RL element-wise kernels (in place) ----------------------------------- */
 int mil_rl_ratio(float *d_T, const float *d_A, size_t n, void *stream);               /* div3Dgpu  src/api_subfunc.cu:333 */
@@ -125,6 +128,12 @@ int mil_corr_padded_pick_kernel(const float *m12);
 /* cost-kernel launches of this thread's last mil_reg3d_affine (records[5] counts evaluations like the reference; repeats of
  * a point just visited are answered from the last results, same value, no launch) */
 int mil_reg3d_last_cost_launches(void);
+/* Audit aid: what this thread's next mil_reg3d_affine / reg3d calls evaluate, in order.  begin(capacity > 0) starts a fresh
+ * trace of up to `capacity` evaluations, begin(0) stops it.  read copies min(max_entries, stored) entries of 13 floats --
+ * the matrix of that evaluation (the reference's global affCoef, src/api_subfunc.cu:2378-2383) and the cost handed to
+ * powell() -- and returns the number of evaluations seen since begin. */
+int mil_reg3d_trace_begin(int capacity);
+int mil_reg3d_trace_read(float *out13, int max_entries);
 /* reg3d_affine1, src/api_subfunc.cu:2733-2994, on device-resident volumes of equal size */
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mil_set_device": (C.c_int, [C.c_int]),
     "mil_snap_transform_size": (C.c_int, [C.c_int]),
     "mil_release_cached_memory": (C.c_size_t, []),
+    "mil_cached_memory_bytes": (C.c_size_t, []),
     "mil_set_texture_weight_bits": (C.c_int, [C.c_int]),
     "mil_rl_ratio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mil_rl_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "mil_corr_sums": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, c_double_p, C.c_void_p]),
     "mil_padded_source_eligible": (C.c_int, [C.c_int] * 6),
     "mil_reg3d_last_cost_launches": (C.c_int, []),
+    "mil_reg3d_trace_begin": (C.c_int, [C.c_int]),
+    "mil_reg3d_trace_read": (C.c_int, [c_float_p, C.c_int]),
     "mil_corr_padded_force_kernel": (C.c_int, [C.c_int]),
     "mil_corr_padded_pick_kernel": (C.c_int, [c_float_p]),
     "mil_padded_source_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),

@@ -2,17 +2,35 @@
 // onto view A according to the registration mode, joint Richardson-Lucy deconvolution, projections.
 // Same 34 (or 36) positional arguments, folder layout, matrix files and log as the reference tool
 // (src/spim_fusion_batch.cpp:58-113, 135-190, 262-296, 613-966) -- "set same with the ImageJ diSPIMFusion plugin".
-// One process, one GPU, like the reference; the multi-GPU driver that shards time points is microimagelib_amd/batch.py.
-// Unlike the reference the file I/O does not sit in the GPU's way: the next time point's two stacks are read (and
-// converted to float) on a helper thread while this one is registered and deconvolved, and the deconvolved stack is
-// written behind while the projections and the next time point proceed -- at 512 x 512 x 256 the TIFF work is as long
-// as the GPU work.  Same files, same order of results, same log.
+//
+// Multi-GPU: argument 34 may be a comma-separated device list ("0,1,2,3"), or MIL_DEVICES names
+// one; the default is the reference's single device.  One host WORKER THREAD per listed device -- its own HIP context,
+// streams, engine, OTFs and buffers inside libapi.so, which serialises nothing across devices -- and the time points are
+// dealt round-robin over the workers.  No volume ever crosses devices:
+//   regMode 0 / 3   time points are independent;
+//   regMode 1       the test time point is registered first (on the first device), then as regMode 0;
+//   regMode 2       the starting matrix of time point i is the running average of the previous results
+//                   (src/spim_fusion_batch.cpp:786-808): the chain state -- 24 floats -- is handed from the worker of
+//                   time point i-1 to the worker of i, which has its stacks loaded and preprocessed by then; it registers,
+//                   hands the state on and only then deconvolves.
+// Results, file names and matrix files are those of the single-device run bit for bit; ProcessingLog.txt is written in
+// time-point order whichever worker finishes first.  A device may be listed twice ("0,0"): two workers then share it.
+//
+// Unlike the reference the file I/O does not sit in the GPU's way: each worker reads (and converts to float) its next time
+// point's two stacks on a helper thread while this one is registered and deconvolved, and writes the deconvolved stack
+// behind while the projections and the next time point proceed -- at 512 x 512 x 256 the TIFF work is as long as the GPU
+// work.
 #include <sys/stat.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <future>
+#include <map>
+#include <mutex>
+#include <thread>
 #include <utility>
 
 #include "cli_common.h"
@@ -62,21 +80,70 @@ void usage(bool full) {
 
 unsigned int scaled(unsigned int n, float num, float den) { return (unsigned int)std::lround((float)n * num / den); }
 
+// ProcessingLog.txt + stdout.  A worker collects the text of its time point and hands it over when the time point is
+// done; the texts are written in time-point order whichever worker finishes first (with one worker: as they come).
 struct Log {
     std::string path;
-    void operator()(const char *fmt, ...) const __attribute__((format(printf, 2, 3))) {
-        va_list ap, ap2;
-        va_start(ap, fmt);
-        va_copy(ap2, ap);
-        vprintf(fmt, ap);
-        va_end(ap);
+    std::mutex mu;
+    std::map<int, std::string> waiting;  // time-point index -> text, not yet written
+    int next = 0;
+    void emit(const std::string &text) {
+        fputs(text.c_str(), stdout);
+        fflush(stdout);
         if (FILE *f = fopen(path.c_str(), "a")) {
-            vfprintf(f, fmt, ap2);
+            fputs(text.c_str(), f);
             fclose(f);
         }
-        va_end(ap2);
+    }
+    void direct(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        std::lock_guard<std::mutex> lock(mu);
+        emit(buf);
+    }
+    void publish(int index, std::string text) {
+        std::lock_guard<std::mutex> lock(mu);
+        waiting[index] = std::move(text);
+        for (auto it = waiting.find(next); it != waiting.end(); it = waiting.find(next)) {
+            emit(it->second);
+            waiting.erase(it);
+            ++next;
+        }
     }
 };
+
+// text of one time point
+struct Lines {
+    std::string text;
+    void operator()(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        text += buf;
+    }
+};
+
+std::vector<int> parse_devices(const char *arg34) {
+    std::string list = arg34;
+    if (list.find(',') == std::string::npos)
+        if (const char *env = getenv("MIL_DEVICES")) list = env;
+    std::vector<int> out;
+    size_t pos = 0;
+    while (pos <= list.size()) {
+        const size_t comma = list.find(',', pos);
+        const std::string item = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        if (!item.empty()) out.push_back(atoi(item.c_str()));
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+    }
+    if (out.empty()) out.push_back(atoi(arg34));
+    return out;
+}
 
 void write_tmx(const std::string &path, const float *m) {
     FILE *f = fopen(path.c_str(), "w");
@@ -111,7 +178,8 @@ int main(int argc, char **argv) {
     const bool save_3dx = atoi(argv[30]) != 0, save_3dy = atoi(argv[31]) != 0;
     const unsigned short out_bits = (unsigned short)atoi(argv[32]);
     const bool query = atoi(argv[33]) != 0;
-    const int device = atoi(argv[34]);
+    const std::vector<int> devices = parse_devices(argv[34]);
+    const int device = devices[0];
     const bool unmatch = argc == 37;
     if (query) queryDevice();
 
@@ -129,7 +197,8 @@ int main(int argc, char **argv) {
     if (save_yproj) mkdir(mp_zx.c_str(), 0755);
     if (save_3dx) mkdir(mp_3dx.c_str(), 0755);
     if (save_3dy) mkdir(mp_3dy.c_str(), 0755);
-    Log log{out_dir + "ProcessingLog.txt"};
+    Log log;
+    log.path = out_dir + "ProcessingLog.txt";
 
     // ---- geometry from the first time point (:400-452)
     auto name_of = [](const std::string &dir, const std::string &base, int n) { return dir + base + std::to_string(n) + ".tif"; };
@@ -163,192 +232,267 @@ int main(int argc, char **argv) {
     case 3: reg_choice = 4; break;
     default: break;
     }
+    if (reg_mode < 0 || reg_mode > 3) { printf("\tWrong registration mode %d, processing stopped !!!\n", reg_mode); return 1; }
     const int aff_method = 6;
     const float cost_bar = 0.1f;
-    float tmx[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, initial_tmx[12], previous[12], weighted[12];
+    float tmx0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     if (have_itmx) {
         FILE *f = fopen(itmx_path.c_str(), "r");
         if (!f) { printf("***** Input transformation matrix file does not exist: %s\n", itmx_path.c_str()); return 1; }
         for (int i = 0; i < 12; ++i)
-            if (fscanf(f, "%f", &tmx[i]) != 1) { printf("***** Malformed matrix file %s\n", itmx_path.c_str()); fclose(f); return 1; }
+            if (fscanf(f, "%f", &tmx0[i]) != 1) { printf("***** Malformed matrix file %s\n", itmx_path.c_str()); fclose(f); return 1; }
         fclose(f);
     }
-    std::memcpy(previous, tmx, sizeof tmx);
-    std::memcpy(weighted, tmx, sizeof tmx);
 
-    std::vector<float> b_reg(total), decon(total), mp((size_t)(sx * sy + sy * sz + sz * sx));
-    float reg_records[11] = {0}, decon_records[10] = {0};
     const auto t_batch = std::chrono::steady_clock::now();
     auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-    log("\n=== spimFusionBatch: images %d .. %d (step %d), size %lld x %lld x %lld, regMode %d, %d decon iterations\n",
-        n_start, n_end, n_step, sx, sy, sz, reg_mode, iters);
+    log.direct("\n=== spimFusionBatch: images %d .. %d (step %d), size %lld x %lld x %lld, regMode %d, %d decon iterations\n",
+               n_start, n_end, n_step, sx, sy, sz, reg_mode, iters);
+    if (devices.size() > 1) {
+        std::string list;
+        for (size_t i = 0; i < devices.size(); ++i) list += (i ? "," : "") + std::to_string(devices[i]);
+        log.direct("=== %zu workers on GPU devices %s, time points dealt round-robin\n", devices.size(), list.c_str());
+    }
 
-    // read-ahead / write-behind
     typedef std::pair<cli::Volume, cli::Volume> Pair;
     auto load_pair = [&](int n) { return Pair(cli::load_tiff(name_of(dir1, base1, n)), cli::load_tiff(name_of(dir2, base2, n))); };
-    std::future<Pair> ahead;
-    int ahead_n = 0;
-    std::future<void> behind;
-    std::vector<float> decon_out(total);
 
-    bool first = true;
-    for (int n = n_start; n <= n_end; n += n_step) {
-        int reg_choice_now = reg_choice;
-        if (reg_mode == 0) reg_choice_now = 0;          // :614-616
-        else if (reg_mode == 1) n = n_test;             // :617-619: register on the test image first
-        log("\n*** Image time point number: %d \n", n);
-        const auto t0 = std::chrono::steady_clock::now();
-
-        // ---- preprocessing (:666-711)
-        Pair in = (ahead.valid() && ahead_n == n) ? ahead.get() : load_pair(n);
-        if (ahead.valid()) ahead.wait();  // a read-ahead that is not wanted after all (regMode 1 jumps back)
-        {   // next time point: only when both files are there -- a missing file must stop the batch where the
-            // reference stops it, after this time point's results are written
-            const int nn = n + n_step;
-            const bool test_pass = reg_mode == 1 && first;
-            if (!test_pass && nn <= n_end && fexists(const_cast<char *>(name_of(dir1, base1, nn).c_str())) &&
-                fexists(const_cast<char *>(name_of(dir2, base2, nn).c_str()))) {
-                ahead_n = nn;
-                ahead = std::async(std::launch::async, load_pair, nn);
-            }
-        }
-        cli::Volume &a_in = in.first, &b_in = in.second;
-        if (a_in.size[0] != in1[0] || a_in.size[1] != in1[1] || a_in.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); return 1; }
-        if (b_in.size[0] != in2[0] || b_in.size[1] != in2[1] || b_in.size[2] != in2[2]) { printf("\t Input image 2 size does not match !!!\n"); return 1; }
-        // no copies: a stack that needs no resampling / rotation is used where it was read
+    // What one registration needs besides the volumes; the fall-back ladder of the reference (:714-843).
+    struct RegState {
+        float tmx[12], initial_tmx[12];
+        bool have_itmx;
+    };
+    // Preprocessing of one time point (:666-711).  No copies: a stack that needs no resampling / rotation is used where
+    // it was read.
+    struct Prepared {
+        Pair in;
         cli::Volume a_res, b_rot_own, b_res;
-        cli::Volume *a_ptr = &a_in;
+        cli::Volume *a = nullptr, *b = nullptr;
+    };
+    std::atomic<bool> failed{false};
+    auto preprocess = [&](Prepared &p, int dev) -> bool {
+        cli::Volume &a_in = p.in.first, &b_in = p.in.second;
+        if (a_in.size[0] != in1[0] || a_in.size[1] != in1[1] || a_in.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); return false; }
+        if (b_in.size[0] != in2[0] || b_in.size[1] != in2[1] || b_in.size[2] != in2[2]) { printf("\t Input image 2 size does not match !!!\n"); return false; }
+        p.a = &a_in;
         if (a_in.size[0] != size[0] || a_in.size[1] != size[1] || a_in.size[2] != size[2]) {
-            a_res.bits = a_in.bits;
-            a_res.data.resize(total);
-            for (int i = 0; i < 3; ++i) a_res.size[i] = size[i];
-            (void)imresize3d(a_res.data.data(), a_in.data.data(), sx, sy, sz, a_in.size[0], a_in.size[1], a_in.size[2], device);
-            a_ptr = &a_res;
+            p.a_res.bits = a_in.bits;
+            p.a_res.data.resize(total);
+            for (int i = 0; i < 3; ++i) p.a_res.size[i] = size[i];
+            (void)imresize3d(p.a_res.data.data(), a_in.data.data(), sx, sy, sz, a_in.size[0], a_in.size[1], a_in.size[2], dev);
+            p.a = &p.a_res;
         }
         cli::Volume *b_rot_ptr = &b_in;
         if (op_choice != 0) {
-            b_rot_own.bits = b_in.bits;
-            b_rot_own.data.resize(b_in.count());
-            (void)imoperation3D(b_rot_own.data.data(), b_rot_own.size, b_in.data.data(), b_in.size, op_choice, device);
-            b_rot_ptr = &b_rot_own;
+            p.b_rot_own.bits = b_in.bits;
+            p.b_rot_own.data.resize(b_in.count());
+            (void)imoperation3D(p.b_rot_own.data.data(), p.b_rot_own.size, b_in.data.data(), b_in.size, op_choice, dev);
+            b_rot_ptr = &p.b_rot_own;
         }
         cli::Volume &b_rot = *b_rot_ptr;
-        cli::Volume *b_ptr = &b_rot;
+        p.b = &b_rot;
         if (b_rot.size[0] != size2[0] || b_rot.size[1] != size2[1] || b_rot.size[2] != size2[2]) {
-            b_res.bits = b_rot.bits;
-            b_res.data.resize((size_t)size2[0] * size2[1] * size2[2]);
-            for (int i = 0; i < 3; ++i) b_res.size[i] = size2[i];
-            (void)imresize3d(b_res.data.data(), b_rot.data.data(), size2[0], size2[1], size2[2], b_rot.size[0], b_rot.size[1],
-                             b_rot.size[2], device);
-            b_ptr = &b_res;
+            p.b_res.bits = b_rot.bits;
+            p.b_res.data.resize((size_t)size2[0] * size2[1] * size2[2]);
+            for (int i = 0; i < 3; ++i) p.b_res.size[i] = size2[i];
+            (void)imresize3d(p.b_res.data.data(), b_rot.data.data(), size2[0], size2[1], size2[2], b_rot.size[0], b_rot.size[1],
+                             b_rot.size[2], dev);
+            p.b = &p.b_res;
         }
-        cli::Volume &a = *a_ptr, &b = *b_ptr;
-        const auto t1 = std::chrono::steady_clock::now();
-
-        // ---- registration with the reference's fall-back ladder (:714-843)
-        if (have_itmx) std::memcpy(initial_tmx, tmx, sizeof tmx);
-        auto run = [&](int choice, bool use_input) {
-            return reg3d(b_reg.data(), tmx, a.data.data(), b.data.data(), a.size, b.size, choice, aff_method, use_input, ftol,
-                         it_limit, device, -1, true, reg_records);
-        };
-        auto bad = [&] { return !checkmatrix(tmx, sx, sy, sz) || reg_records[3] < cost_bar; };
-        auto ladder = [&] {  // first attempt, other scheme without the input matrix, then the input matrix itself
-            (void)run(reg_choice_now, have_itmx);
-            if (bad()) {
-                log("\n\t... Attempt failed: transformation matrix problematic or cost function value %f < threshold %2.2f\n"
-                    "\n\t... Change scheme and redo the registration!!!\n", reg_records[3], cost_bar);
-                (void)run(reg_choice_now == 4 ? 2 : 4, false);
-                if (bad() && have_itmx) {
-                    log("\n\t... Attempt failed again: use input transformation matrix!!!\n");
-                    std::memcpy(tmx, initial_tmx, sizeof tmx);
-                    (void)run(0, true);
-                }
+        return true;
+    };
+    // One registration attempt / the ladder, on device `dev`, into b_reg; st.tmx in / out.
+    auto run_reg = [&](RegState &st, Prepared &p, std::vector<float> &b_reg, float *rec, int choice, bool use_input, int dev) {
+        return reg3d(b_reg.data(), st.tmx, p.a->data.data(), p.b->data.data(), p.a->size, p.b->size, choice, aff_method, use_input,
+                     ftol, it_limit, dev, -1, true, rec);
+    };
+    auto bad = [&](const RegState &st, const float *rec) {
+        return !checkmatrix(const_cast<float *>(st.tmx), sx, sy, sz) || rec[3] < cost_bar;
+    };
+    auto ladder = [&](RegState &st, Prepared &p, std::vector<float> &b_reg, float *rec, int choice_now, int dev, Lines &out) {
+        // first attempt, other scheme without the input matrix, then the input matrix itself
+        (void)run_reg(st, p, b_reg, rec, choice_now, st.have_itmx, dev);
+        if (bad(st, rec)) {
+            out("\n\t... Attempt failed: transformation matrix problematic or cost function value %f < threshold %2.2f\n"
+                "\n\t... Change scheme and redo the registration!!!\n", rec[3], cost_bar);
+            (void)run_reg(st, p, b_reg, rec, choice_now == 4 ? 2 : 4, false, dev);
+            if (bad(st, rec) && st.have_itmx) {
+                out("\n\t... Attempt failed again: use input transformation matrix!!!\n");
+                std::memcpy(st.tmx, st.initial_tmx, sizeof st.tmx);
+                (void)run_reg(st, p, b_reg, rec, 0, true, dev);
             }
-        };
-        bool restart_batch = false;
-        switch (reg_mode) {
-        case 0: (void)run(0, have_itmx); break;
-        case 1:  // register on the test image, then apply that matrix to every image (:719-751)
-            ladder();
-            reg_mode = 0;
-            have_itmx = true;
-            restart_batch = true;
-            break;
-        case 2:
-            if (first) {
-                ladder();
-                std::memcpy(weighted, tmx, sizeof tmx);
-            } else {  // start from the running average, fall back to the previous matrix (:786-808)
-                have_itmx = true;
-                std::memcpy(tmx, weighted, sizeof tmx);
-                (void)run(2, true);
-                if (bad()) {
-                    log("\n\t... Attempt failed: use previous transformation matrix!!!\n");
-                    std::memcpy(tmx, previous, sizeof tmx);
-                    (void)run(0, true);
-                }
-                for (int j = 0; j < 12; ++j) weighted[j] = (float)(0.8 * weighted[j] + 0.2 * tmx[j]);  // double arithmetic, :805-807
-            }
-            std::memcpy(previous, tmx, sizeof tmx);
-            break;
-        case 3:
-            if (have_itmx) std::memcpy(tmx, initial_tmx, sizeof tmx);
-            ladder();
-            break;
-        default: printf("\tWrong registration mode %d, processing stopped !!!\n", reg_mode); return 1;
         }
-        first = false;
-        if (restart_batch) { n = n_start - n_step; continue; }
-        log("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
-            reg_records[1], reg_records[3], reg_records[7]);
-        const std::string ns = std::to_string(n);
-        write_tmx(tmx_dir + "Matrix_" + ns + ".tmx", tmx);  // always saved (:859-868)
-        if (save_reg1) writetifstack(const_cast<char *>((reg1_dir + base1 + "reg_" + ns + ".tif").c_str()), a.data.data(), size, (unsigned short)in_bits);
-        if (save_reg2) writetifstack(const_cast<char *>((reg2_dir + base2 + "reg_" + ns + ".tif").c_str()), b_reg.data(), size, (unsigned short)in_bits);
-        const auto t2 = std::chrono::steady_clock::now();
+    };
 
-        // ---- joint deconvolution (:874-911)
-        (void)decon_dualview(decon.data(), a.data.data(), b_reg.data(), size, psf1.data.data(), psf2.data.data(), psf1.size, false,
-                             iters, device, -1, true, decon_records, unmatch, bp1.data.data(), bp2.data.data());
-        log("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
-            decon_records[5]);
-        if (behind.valid()) behind.get();  // the previous stack has left decon_out
-        decon_out.swap(decon);             // projections below read decon_out; decon is scratch again
-        {
-            const std::string path = decon_dir + "Decon_" + ns + ".tif";
-            const float *data = decon_out.data();
-            unsigned int wsize[3] = {size[0], size[1], size[2]};
-            const unsigned short bits = out_bits;
-            behind = std::async(std::launch::async, [path, data, wsize, bits]() mutable {
-                writetifstack(const_cast<char *>(path.c_str()), const_cast<float *>(data), wsize, bits);
-            });
-        }
-        const auto t3 = std::chrono::steady_clock::now();
-
-        // ---- projections (:913-943)
-        if (save_zproj || save_xproj || save_yproj) {
-            unsigned int mp_size[6];
-            (void)mp2dgpu(mp.data(), mp_size, decon_out.data(), size, save_zproj, save_xproj, save_yproj);
-            unsigned int s2[3] = {0, 0, 1};
-            if (save_zproj) { s2[0] = mp_size[0]; s2[1] = mp_size[1]; writetifstack(const_cast<char *>((mp_xy + "MP_XY_" + ns + ".tif").c_str()), mp.data(), s2, out_bits); }
-            if (save_xproj) { s2[0] = mp_size[2]; s2[1] = mp_size[3]; writetifstack(const_cast<char *>((mp_yz + "MP_YZ_" + ns + ".tif").c_str()), mp.data() + sx * sy, s2, out_bits); }
-            if (save_yproj) { s2[0] = mp_size[4]; s2[1] = mp_size[5]; writetifstack(const_cast<char *>((mp_zx + "MP_ZX_" + ns + ".tif").c_str()), mp.data() + sx * sy + sy * sz, s2, out_bits); }
-        }
-        for (int axis = 1; axis <= 2; ++axis) {
-            if (!(axis == 1 ? save_3dx : save_3dy)) continue;
-            const long long project_num = 36;
-            const long long rot = (long long)std::llround(std::sqrt(axis == 1 ? (double)(sy * sy + sz * sz) : (double)(sx * sx + sz * sz)));
-            std::vector<float> mp3d((size_t)((axis == 1 ? sx : sy) * rot * project_num));
-            unsigned int s3[3];
-            (void)mip3dgpu(mp3d.data(), s3, decon_out.data(), size, axis, project_num);
-            writetifstack(const_cast<char *>(((axis == 1 ? mp_3dx + "MP_3D_Xaxis_" : mp_3dy + "MP_3D_Yaxis_") + ns + ".tif").c_str()),
-                          mp3d.data(), s3, out_bits);
-        }
-        const auto t4 = std::chrono::steady_clock::now();
-        log("\tTime cost: preprocessing %2.3f s, registration %2.3f s, deconvolution %2.3f s, projections %2.3f s\n", sec(t0, t1),
-            sec(t1, t2), sec(t2, t3), sec(t3, t4));
+    // ---- regMode 1: register on the test image first (on the first device), then apply that matrix to every image
+    // (:719-751).  Nothing is written for this pass.
+    RegState base;
+    std::memcpy(base.tmx, tmx0, sizeof tmx0);
+    std::memcpy(base.initial_tmx, tmx0, sizeof tmx0);
+    base.have_itmx = have_itmx;
+    if (reg_mode == 1) {
+        Lines out;
+        out("\n*** Image time point number: %d \n", n_test);
+        Prepared p;
+        p.in = load_pair(n_test);
+        if (!preprocess(p, device)) return 1;
+        std::vector<float> b_reg(total);
+        float rec[11] = {0};
+        ladder(base, p, b_reg, rec, reg_choice, device, out);
+        log.direct("%s", out.text.c_str());
+        reg_mode = 0;
+        base.have_itmx = true;
+        std::memcpy(base.initial_tmx, base.tmx, sizeof base.tmx);
     }
-    if (behind.valid()) behind.get();
-    log("\n=== Batch processing completed, whole time cost: %2.3f s\n", sec(t_batch, std::chrono::steady_clock::now()));
+
+    std::vector<int> points;
+    for (int n = n_start; n <= n_end; n += n_step) points.push_back(n);
+
+    // ---- regMode 2: the chain state travels from the worker of time point i-1 to the worker of i
+    struct Chain {
+        std::mutex mu;
+        std::condition_variable cv;
+        int next = 0;  // index of the time point whose registration may start
+        float weighted[12], previous[12];
+        bool have_itmx;
+    } chain;
+    std::memcpy(chain.weighted, tmx0, sizeof tmx0);
+    std::memcpy(chain.previous, tmx0, sizeof tmx0);
+    chain.have_itmx = have_itmx;
+
+    auto worker = [&](int w) {
+        const int dev = devices[(size_t)w];
+        const int n_workers = (int)devices.size();
+        std::vector<float> b_reg(total), decon(total), decon_out(total), mp((size_t)(sx * sy + sy * sz + sz * sx));
+        float reg_records[11] = {0}, decon_records[10] = {0};
+        std::future<Pair> ahead;
+        size_t ahead_i = 0;
+        std::future<void> behind;
+        auto stop = [&](int index) {  // a failed worker must not leave the others waiting for the chain or the log
+            failed = true;
+            {
+                std::lock_guard<std::mutex> lock(chain.mu);
+                chain.next = (int)points.size() + 1;
+            }
+            chain.cv.notify_all();
+            (void)index;
+        };
+        for (size_t i = (size_t)w; i < points.size() && !failed; i += (size_t)n_workers) {
+            const int n = points[i];
+            Lines out;
+            out("\n*** Image time point number: %d \n", n);
+            const auto t0 = std::chrono::steady_clock::now();
+
+            // ---- stacks: read ahead by this worker's previous time point, or read now
+            Prepared p;
+            p.in = (ahead.valid() && ahead_i == i) ? ahead.get() : load_pair(n);
+            {   // this worker's next time point: only when both files are there -- a missing file must stop the batch where
+                // the reference stops it, after the earlier time points' results are written
+                const size_t ni = i + (size_t)n_workers;
+                if (ni < points.size() && fexists(const_cast<char *>(name_of(dir1, base1, points[ni]).c_str())) &&
+                    fexists(const_cast<char *>(name_of(dir2, base2, points[ni]).c_str()))) {
+                    ahead_i = ni;
+                    ahead = std::async(std::launch::async, load_pair, points[ni]);
+                }
+            }
+            if (!preprocess(p, dev)) { stop((int)i); break; }
+            cli::Volume &a = *p.a;
+            const auto t1 = std::chrono::steady_clock::now();
+
+            // ---- registration (:714-843)
+            RegState st = base;
+            switch (reg_mode) {
+            case 0: (void)run_reg(st, p, b_reg, reg_records, 0, st.have_itmx, dev); break;
+            case 2: {
+                std::unique_lock<std::mutex> lock(chain.mu);
+                chain.cv.wait(lock, [&] { return chain.next >= (int)i; });
+                if (chain.next != (int)i) break;  // another worker failed
+                lock.unlock();  // the state is this worker's alone until it advances `next`
+                if (i == 0) {
+                    ladder(st, p, b_reg, reg_records, reg_choice, dev, out);
+                    std::memcpy(chain.weighted, st.tmx, sizeof st.tmx);
+                } else {  // start from the running average, fall back to the previous matrix (:786-808)
+                    std::memcpy(st.tmx, chain.weighted, sizeof st.tmx);
+                    (void)run_reg(st, p, b_reg, reg_records, 2, true, dev);
+                    if (bad(st, reg_records)) {
+                        out("\n\t... Attempt failed: use previous transformation matrix!!!\n");
+                        std::memcpy(st.tmx, chain.previous, sizeof st.tmx);
+                        (void)run_reg(st, p, b_reg, reg_records, 0, true, dev);
+                    }
+                    for (int j = 0; j < 12; ++j) chain.weighted[j] = (float)(0.8 * chain.weighted[j] + 0.2 * st.tmx[j]);  // double arithmetic, :805-807
+                }
+                std::memcpy(chain.previous, st.tmx, sizeof st.tmx);
+                lock.lock();
+                chain.next = (int)i + 1;
+                lock.unlock();
+                chain.cv.notify_all();
+                break;
+            }
+            case 3: ladder(st, p, b_reg, reg_records, reg_choice, dev, out); break;
+            }
+            if (failed) break;
+            out("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
+                reg_records[1], reg_records[3], reg_records[7]);
+            const std::string ns = std::to_string(n);
+            write_tmx(tmx_dir + "Matrix_" + ns + ".tmx", st.tmx);  // always saved (:859-868)
+            if (save_reg1) writetifstack(const_cast<char *>((reg1_dir + base1 + "reg_" + ns + ".tif").c_str()), a.data.data(), size, (unsigned short)in_bits);
+            if (save_reg2) writetifstack(const_cast<char *>((reg2_dir + base2 + "reg_" + ns + ".tif").c_str()), b_reg.data(), size, (unsigned short)in_bits);
+            const auto t2 = std::chrono::steady_clock::now();
+
+            // ---- joint deconvolution (:874-911)
+            (void)decon_dualview(decon.data(), a.data.data(), b_reg.data(), size, psf1.data.data(), psf2.data.data(), psf1.size, false,
+                                 iters, dev, -1, true, decon_records, unmatch, bp1.data.data(), bp2.data.data());
+            out("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
+                decon_records[5]);
+            if (behind.valid()) behind.get();  // the previous stack has left decon_out
+            decon_out.swap(decon);             // projections below read decon_out; decon is scratch again
+            {
+                const std::string path = decon_dir + "Decon_" + ns + ".tif";
+                const float *data = decon_out.data();
+                unsigned int wsize[3] = {size[0], size[1], size[2]};
+                const unsigned short bits = out_bits;
+                behind = std::async(std::launch::async, [path, data, wsize, bits]() mutable {
+                    writetifstack(const_cast<char *>(path.c_str()), const_cast<float *>(data), wsize, bits);
+                });
+            }
+            const auto t3 = std::chrono::steady_clock::now();
+
+            // ---- projections (:913-943)
+            if (save_zproj || save_xproj || save_yproj) {
+                unsigned int mp_size[6];
+                (void)mp2dgpu(mp.data(), mp_size, decon_out.data(), size, save_zproj, save_xproj, save_yproj);
+                unsigned int s2[3] = {0, 0, 1};
+                if (save_zproj) { s2[0] = mp_size[0]; s2[1] = mp_size[1]; writetifstack(const_cast<char *>((mp_xy + "MP_XY_" + ns + ".tif").c_str()), mp.data(), s2, out_bits); }
+                if (save_xproj) { s2[0] = mp_size[2]; s2[1] = mp_size[3]; writetifstack(const_cast<char *>((mp_yz + "MP_YZ_" + ns + ".tif").c_str()), mp.data() + sx * sy, s2, out_bits); }
+                if (save_yproj) { s2[0] = mp_size[4]; s2[1] = mp_size[5]; writetifstack(const_cast<char *>((mp_zx + "MP_ZX_" + ns + ".tif").c_str()), mp.data() + sx * sy + sy * sz, s2, out_bits); }
+            }
+            for (int axis = 1; axis <= 2; ++axis) {
+                if (!(axis == 1 ? save_3dx : save_3dy)) continue;
+                const long long project_num = 36;
+                const long long rot = (long long)std::llround(std::sqrt(axis == 1 ? (double)(sy * sy + sz * sz) : (double)(sx * sx + sz * sz)));
+                std::vector<float> mp3d((size_t)((axis == 1 ? sx : sy) * rot * project_num));
+                unsigned int s3[3];
+                (void)mip3dgpu(mp3d.data(), s3, decon_out.data(), size, axis, project_num);
+                writetifstack(const_cast<char *>(((axis == 1 ? mp_3dx + "MP_3D_Xaxis_" : mp_3dy + "MP_3D_Yaxis_") + ns + ".tif").c_str()),
+                              mp3d.data(), s3, out_bits);
+            }
+            const auto t4 = std::chrono::steady_clock::now();
+            out("\tTime cost: preprocessing %2.3f s, registration %2.3f s, deconvolution %2.3f s, projections %2.3f s\n", sec(t0, t1),
+                sec(t1, t2), sec(t2, t3), sec(t3, t4));
+            log.publish((int)i, std::move(out.text));
+        }
+        if (ahead.valid()) ahead.wait();
+        if (behind.valid()) behind.get();
+    };
+
+    if (devices.size() == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (int w = 0; w < (int)devices.size(); ++w) threads.emplace_back(worker, w);
+        for (auto &t : threads) t.join();
+    }
+    if (failed) return 1;
+    log.direct("\n=== Batch processing completed, whole time cost: %2.3f s\n", sec(t_batch, std::chrono::steady_clock::now()));
     return 0;
 }

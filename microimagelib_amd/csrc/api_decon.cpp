@@ -125,10 +125,16 @@ void download_volume(float *h_dst, float *d_src, float *d_stage, const Geometry 
 }
 
 // What a libapi.h deconvolution call keeps for the next one (the reference rebuilds all of it per call,
-// src/api_decon.cpp:198-223: plans, work areas and two to four OTFs): the engine of the last (device, box) with its tables
-// and scratch, and the OTFs it made, found again by comparing the PSF bytes.  A time-lapse batch calls with the same box
-// and the same PSFs for every time point.  Results are those of an uncached call, bit for bit (same kernels on the
-// same data); MIL_DECON_CACHE=0 disables it, mil_release_cached_memory() drops it.
+// src/api_decon.cpp:198-223: plans, work areas and two to four OTFs): engines with their tables and scratch, keyed by
+// (device, FFT box), and the OTFs each made, found again by comparing the PSF bytes.  A time-lapse batch calls with the
+// same box and the same PSFs for every time point.  Results are those of an uncached call, bit for bit (same kernels on
+// the same data); MIL_DECON_CACHE=0 disables it, mil_release_cached_memory() drops it.
+//
+// Several host threads may deconvolve at once -- one per GPU of a node (the reference's deviceNum), or several on one GPU:
+// an entry is CHECKED OUT for the duration of a call (the registry lock is held for the look-up only), a second caller
+// with the same key gets a second entry.  At most kEntriesPerDevice idle-or-busy entries are kept per device (least
+// recently used idle one evicted); a caller that finds them all busy with other keys works on a private entry that is
+// destroyed when it returns.
 struct DeconCache {
     struct Otf {
         std::vector<float> psf;  // host copy: a hit is a full comparison, not a hash match
@@ -137,16 +143,105 @@ struct DeconCache {
         DeviceBuffer<float2> buf;
         unsigned long long stamp;
     };
-    std::mutex mu;
-    int device = -1;
-    Dims box{0, 0, 0};
-    std::unique_ptr<DeconEngine> eng;
-    std::vector<std::unique_ptr<Otf>> otfs;
+    struct Entry {
+        int device = -1;
+        Dims box{0, 0, 0};
+        std::unique_ptr<DeconEngine> eng;
+        std::vector<std::unique_ptr<Otf>> otfs;
+        unsigned long long clock = 0;  // OTF recency
+        unsigned long long used = 0;   // entry recency (registry clock)
+        bool busy = false;
+        bool cached = true;            // false: private to one call
+        ~Entry() {                     // engine, stream and buffers belong to `device`
+            if (!eng && otfs.empty()) return;
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != device && device >= 0) (void)hipSetDevice(device);
+            otfs.clear();
+            eng.reset();
+            if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+        }
+    };
+    static constexpr size_t kEntriesPerDevice = 2;
+    std::mutex mu;  // registry only: never held while an engine works
+    std::vector<std::unique_ptr<Entry>> entries;
     unsigned long long clock = 0;
-    void drop() {
-        otfs.clear();
-        eng.reset();
-        device = -1;
+
+    // The calling thread has `device` current.
+    Entry *checkout(int device, Dims box, bool enabled) {
+        std::unique_ptr<Entry> doomed;  // destroyed after the lock is released (its destructor waits for the device)
+        Entry *e = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (enabled) {
+                size_t on_device = 0;
+                for (auto &c : entries) {
+                    if (c->device != device) continue;
+                    ++on_device;
+                    if (!e && !c->busy && c->box == box) e = c.get();
+                }
+                if (!e && on_device >= kEntriesPerDevice) {  // evict the least recently used idle entry of this device
+                    size_t lru = entries.size();
+                    for (size_t i = 0; i < entries.size(); ++i)
+                        if (entries[i]->device == device && !entries[i]->busy &&
+                            (lru == entries.size() || entries[i]->used < entries[lru]->used))
+                            lru = i;
+                    if (lru != entries.size()) {
+                        doomed = std::move(entries[lru]);
+                        entries.erase(entries.begin() + (long)lru);
+                        --on_device;
+                    }
+                }
+                if (!e && on_device < kEntriesPerDevice) {
+                    entries.emplace_back(new Entry());
+                    e = entries.back().get();
+                    e->device = device;
+                    e->box = box;
+                }
+            }
+            if (e) {
+                e->busy = true;
+                e->used = ++clock;
+            }
+        }
+        doomed.reset();
+        if (!e) {  // cache off, or every entry of this device busy with another box: private
+            e = new Entry();
+            e->device = device;
+            e->box = box;
+            e->busy = true;
+            e->cached = false;
+        }
+        try {
+            if (!e->eng) e->eng.reset(new DeconEngine(box, nullptr));
+        } catch (...) {
+            checkin(e);
+            throw;
+        }
+        return e;
+    }
+    void checkin(Entry *e) {
+        if (!e->cached) {
+            delete e;
+            return;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        e->busy = false;
+    }
+    // Destroys every idle entry; busy ones finish their call first and stay (their owners may drop them later).
+    void drop_idle() {
+        std::vector<std::unique_ptr<Entry>> doomed;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            for (size_t i = 0; i < entries.size();)
+                if (!entries[i]->busy) {
+                    doomed.push_back(std::move(entries[i]));
+                    entries.erase(entries.begin() + (long)i);
+                } else {
+                    ++i;
+                }
+        }
+        doomed.clear();
     }
 };
 
@@ -160,18 +255,18 @@ bool cache_enabled() {
     return !(v && v[0] == '0');
 }
 
-DeconEngine &cached_engine(DeconCache &c, int device, Dims box) {
-    if (!c.eng || c.device != device || c.box != box) {
-        c.drop();
-        c.eng.reset(new DeconEngine(box, nullptr));
-        c.device = device;
-        c.box = box;
-    }
-    return *c.eng;
-}
+// RAII check-out of a cache entry for one libapi.h call.
+struct CacheLease {
+    DeconCache::Entry *e;
+    CacheLease(int device, Dims box) : e(decon_cache().checkout(device, box, cache_enabled())) {}
+    ~CacheLease() { decon_cache().checkin(e); }
+    CacheLease(const CacheLease &) = delete;
+    CacheLease &operator=(const CacheLease &) = delete;
+    DeconEngine &engine() { return *e->eng; }
+};
 
 // OTF of (psf, flip) for the cached engine: reused when the same PSF bytes were seen before, made otherwise.
-const float2 *cached_otf(DeconCache &c, DeconEngine &eng, const float *h_psf, bool flip, float *d_psf_stage,
+const float2 *cached_otf(DeconCache::Entry &c, DeconEngine &eng, const float *h_psf, bool flip, float *d_psf_stage,
                          const Geometry &g) {
     constexpr size_t kMaxOtfs = 8;  // two views x (OTF, back projector) x two PSF sets
     for (auto &o : c.otfs)
@@ -200,7 +295,7 @@ const float2 *cached_otf(DeconCache &c, DeconEngine &eng, const float *h_psf, bo
 }
 
 // OTF + back-projector OTF for one view (reference src/api_decon.cpp:211-223): matched back projector = flipped PSF.
-void view_otfs(DeconCache &c, DeconEngine &eng, const float2 *&otf, const float2 *&otf_bp, float *d_psf_stage,
+void view_otfs(DeconCache::Entry &c, DeconEngine &eng, const float2 *&otf, const float2 *&otf_bp, float *d_psf_stage,
                const float *h_psf, const float *h_psf_bp, bool unmatch, const Geometry &g) {
     otf = cached_otf(c, eng, h_psf, false, d_psf_stage, g);
     otf_bp = unmatch ? cached_otf(c, eng, h_psf_bp, false, d_psf_stage, g) : cached_otf(c, eng, h_psf, true, d_psf_stage, g);
@@ -209,11 +304,7 @@ void view_otfs(DeconCache &c, DeconEngine &eng, const float2 *&otf, const float2
 }  // namespace
 
 namespace mil {
-void decon_cache_drop() {
-    DeconCache &c = decon_cache();
-    std::lock_guard<std::mutex> lock(c.mu);
-    c.drop();
-}
+void decon_cache_drop() { decon_cache().drop_idle(); }
 }  // namespace mil
 
 extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSize, float *h_psf,
@@ -249,10 +340,9 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         deconRecords[0] = (float)mode;
         const double t_init = now_s();
 
-        DeconCache &cache = decon_cache();
-        std::lock_guard<std::mutex> lock(cache.mu);
-        if (!cache_enabled()) cache.drop();
-        DeconEngine &eng = cached_engine(cache, deviceNum, g.box);
+        CacheLease lease(deviceNum, g.box);  // this call's engine + OTFs; other threads / devices proceed in parallel
+        DeconCache::Entry &cache = *lease.e;
+        DeconEngine &eng = lease.engine();
         hipStream_t s = eng.stream();
         DeviceBuffer<float> dA(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
         deconRecords[2] = free_mb();
@@ -275,7 +365,6 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         deconRecords[7] = (float)(t_loop - t_init);
         deconRecords[8] = (float)(t_done - t_loop);
         deconRecords[9] = (float)(t_end - t_start);
-        if (!cache_enabled()) cache.drop();
         return 0;
     });
 }
@@ -312,10 +401,9 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         deconRecords[0] = (float)mode;
         const double t_init = now_s();
 
-        DeconCache &cache = decon_cache();
-        std::lock_guard<std::mutex> lock(cache.mu);
-        if (!cache_enabled()) cache.drop();
-        DeconEngine &eng = cached_engine(cache, deviceNum, g.box);
+        CacheLease lease(deviceNum, g.box);  // this call's engine + OTFs; other threads / devices proceed in parallel
+        DeconCache::Entry &cache = *lease.e;
+        DeconEngine &eng = lease.engine();
         hipStream_t s = eng.stream();
         DeviceBuffer<float> dA(g.n_box), dB(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
         deconRecords[2] = free_mb();
@@ -341,7 +429,6 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         deconRecords[8] = (float)(t_done - t_loop);
         deconRecords[9] = (float)(t_end - t_start);
         if (verbose) printf("\t... deconvolution done !!! \n");
-        if (!cache_enabled()) cache.drop();
         return 0;
     });
 }

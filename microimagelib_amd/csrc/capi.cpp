@@ -89,6 +89,7 @@ size_t mil_release_cached_memory(void) {
     decon_cache_drop();
     return pool_release_all();
 }
+size_t mil_cached_memory_bytes(void) { return pool_cached_bytes(); }
 
 int mil_rl_ratio(float *d_T, const float *d_A, size_t n, void *stream) {
     return guarded("mil_rl_ratio", [&] { k::rl_ratio(d_T, d_A, n, as_stream(stream)); return 0; });
@@ -301,6 +302,11 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
     });
 }
 int mil_reg3d_last_cost_launches(void) { return reg3d_last_cost_launches(); }
+int mil_reg3d_trace_begin(int capacity) {
+    reg3d_trace_begin(capacity);
+    return 0;
+}
+int mil_reg3d_trace_read(float *out13, int max_entries) { return reg3d_trace_read(out13, max_entries); }
 int mil_reg3d_affine(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, int nx, int ny, int nz,
                      int affMethod, int flagTmx, float FTOL, int itLimit, int verbose, float *records, void *stream) {
     return guarded("mil_reg3d_affine", [&] {

@@ -1,13 +1,21 @@
 // Device-memory pool behind DeviceBuffer.  The reference allocates and frees every device buffer inside each libapi.h
 // call (src/api_decon.cpp:198-253: five cudaMalloc / cudaFree of ~1.9 GB per deconvolution); a time-lapse batch makes the
-// same calls with the same sizes thousands of times.  Freed blocks are kept (per device, by size) and handed out again;
-// MIL_POOL_MB caps what is kept (default 16384 MB, 0 = no pooling), mil_release_cached_memory() gives it back.
+// same calls with the same sizes thousands of times.  Freed blocks are kept (per device, by size) and handed out again.
+//   * MIL_POOL_MB caps what is kept PER DEVICE (default: 6144 MB or 1/16 of the device, whichever is smaller; 0 = no
+//     pooling).  Beyond the cap the blocks freed longest ago go back to the driver (least recently freed first).
+//   * mil_release_cached_memory() gives everything back (a host that shares the device with torch's or rocFFT's own
+//     allocators calls it between phases).
+//   * A block is synchronised on ITS device before it is reused, whichever device is current in the calling thread.
+#include <dlfcn.h>
+
+#include <list>
 #include <map>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
 
 #include "mil_common.h"
+#include "trace.h"
 
 namespace mil {
 
@@ -18,21 +26,55 @@ struct Block {
     int device;
 };
 
+struct Cached {
+    void *p;
+    size_t bytes;
+    int device;
+};
+
 struct Pool {
     std::mutex mu;
-    std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;  // (device, bytes) -> blocks
-    std::unordered_map<void *, Block> live;                             // every block handed out
-    size_t cached_bytes = 0;
-    size_t cap_bytes;
+    std::list<Cached> lru;  // front = freed longest ago
+    std::map<std::pair<int, size_t>, std::vector<std::list<Cached>::iterator>> free_blocks;  // (device, bytes) -> blocks
+    std::unordered_map<void *, Block> live;                                                   // every block handed out
+    std::map<int, size_t> cached_bytes, cap_bytes;                                            // per device
+    long long cap_env_mb = -1;
     Pool() {
-        const char *v = getenv("MIL_POOL_MB");
-        cap_bytes = (size_t)(v ? atoll(v) : 16384) << 20;
+        if (const char *v = getenv("MIL_POOL_MB")) cap_env_mb = atoll(v);
+    }
+    size_t cap_of(int device) {
+        auto it = cap_bytes.find(device);
+        if (it != cap_bytes.end()) return it->second;
+        size_t cap;
+        if (cap_env_mb >= 0) {
+            cap = (size_t)cap_env_mb << 20;
+        } else {
+            cap = (size_t)6144 << 20;
+            size_t free_b = 0, total_b = 0;
+            int cur = 0;
+            if (hipGetDevice(&cur) == hipSuccess && cur == device && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                total_b / 16 < cap)
+                cap = total_b / 16;
+        }
+        cap_bytes[device] = cap;
+        return cap;
+    }
+    void drop_locked(std::list<Cached>::iterator it) {
+        auto &vec = free_blocks[{it->device, it->bytes}];
+        for (size_t i = 0; i < vec.size(); ++i)
+            if (vec[i] == it) {
+                vec.erase(vec.begin() + (long)i);
+                break;
+            }
+        cached_bytes[it->device] -= it->bytes;
+        (void)hipFree(it->p);
+        lru.erase(it);
     }
     void release_all_locked() {
-        for (auto &kv : free_blocks)
-            for (void *p : kv.second) (void)hipFree(p);
+        for (auto &c : lru) (void)hipFree(c.p);
+        lru.clear();
         free_blocks.clear();
-        cached_bytes = 0;
+        cached_bytes.clear();
     }
 };
 
@@ -46,6 +88,49 @@ size_t round_up(size_t bytes) {
     return (bytes + g - 1) / g * g;
 }
 
+// Runs f with `device` current, restoring the caller's device afterwards.
+template <class F>
+void on_device(int device, F &&f) noexcept {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    f();
+    if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+}
+
+int device_of(void *p) {
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lock(pl.mu);
+    auto it = pl.live.find(p);
+    return it == pl.live.end() ? -1 : it->second.device;
+}
+
+void give_back(void *p) noexcept {
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lock(pl.mu);
+    auto it = pl.live.find(p);
+    if (it == pl.live.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    const Block b = it->second;
+    pl.live.erase(it);
+    const size_t cap = pl.cap_of(b.device);
+    if (b.bytes > cap) {
+        (void)hipFree(p);
+        return;
+    }
+    // make room: least recently freed blocks of this device first
+    for (auto c = pl.lru.begin(); c != pl.lru.end() && pl.cached_bytes[b.device] + b.bytes > cap;) {
+        auto next = std::next(c);
+        if (c->device == b.device) pl.drop_locked(c);
+        c = next;
+    }
+    pl.lru.push_back(Cached{p, b.bytes, b.device});
+    pl.free_blocks[{b.device, b.bytes}].push_back(std::prev(pl.lru.end()));
+    pl.cached_bytes[b.device] += b.bytes;
+}
+
 }  // namespace
 
 void *pool_alloc(size_t bytes) {
@@ -57,9 +142,11 @@ void *pool_alloc(size_t bytes) {
     std::lock_guard<std::mutex> lock(pl.mu);
     auto it = pl.free_blocks.find({dev, sz});
     if (it != pl.free_blocks.end() && !it->second.empty()) {
-        void *p = it->second.back();
+        auto c = it->second.back();
         it->second.pop_back();
-        pl.cached_bytes -= sz;
+        void *p = c->p;
+        pl.cached_bytes[dev] -= sz;
+        pl.lru.erase(c);
         pl.live[p] = Block{sz, dev};
         return p;
     }
@@ -75,14 +162,13 @@ void *pool_alloc(size_t bytes) {
     return p;
 }
 
-namespace {
-void give_back(void *p) noexcept;
-}
-
 void pool_free(void *p) noexcept {
     if (!p) return;
-    // hipFree waits for the device; callers rely on that (a buffer may go out of scope behind work still queued)
-    (void)hipDeviceSynchronize();
+    // hipFree waits for the device; callers rely on that (a buffer may go out of scope behind work still queued).  The
+    // device to wait for is the BLOCK's, not whichever one the calling thread has current.
+    const int dev = device_of(p);
+    if (dev >= 0) on_device(dev, [] { (void)hipDeviceSynchronize(); });
+    else (void)hipDeviceSynchronize();
     give_back(p);
 }
 
@@ -92,32 +178,40 @@ void pool_free_after(void *p, hipStream_t s) noexcept {
     give_back(p);
 }
 
-namespace {
-void give_back(void *p) noexcept {
-    Pool &pl = pool();
-    std::lock_guard<std::mutex> lock(pl.mu);
-    auto it = pl.live.find(p);
-    if (it == pl.live.end()) {
-        (void)hipFree(p);
-        return;
-    }
-    const Block b = it->second;
-    pl.live.erase(it);
-    if (pl.cached_bytes + b.bytes > pl.cap_bytes) {
-        (void)hipFree(p);
-        return;
-    }
-    pl.free_blocks[{b.device, b.bytes}].push_back(p);
-    pl.cached_bytes += b.bytes;
-}
-}  // namespace
-
 size_t pool_release_all() {
     Pool &pl = pool();
     std::lock_guard<std::mutex> lock(pl.mu);
-    const size_t n = pl.cached_bytes;
+    size_t n = 0;
+    for (auto &kv : pl.cached_bytes) n += kv.second;
     pl.release_all_locked();
     return n;
+}
+
+size_t pool_cached_bytes() {
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lock(pl.mu);
+    size_t n = 0;
+    for (auto &kv : pl.cached_bytes) n += kv.second;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// roctx hooks of trace.h
+// ---------------------------------------------------------------------------------------------------------------------
+const TraceHooks &trace_hooks() {
+    static const TraceHooks hooks = [] {
+        TraceHooks h;
+        const char *v = getenv("MIL_TRACE");
+        if (v && v[0] == '0') return h;
+        void *lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return h;  // a ROCm install without rocprofiler-sdk: ranges are no-ops
+        h.push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+        h.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!h.push || !h.pop) h.push = nullptr, h.pop = nullptr;
+        return h;
+    }();
+    return hooks;
 }
 
 }  // namespace mil

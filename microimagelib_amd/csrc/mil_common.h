@@ -44,6 +44,7 @@ void *pool_alloc(size_t bytes);
 void pool_free(void *p) noexcept;               // waits for the whole device first, like hipFree
 void pool_free_after(void *p, hipStream_t s) noexcept;  // waits for `s` only: the caller knows no other stream uses p
 size_t pool_release_all();  // hipFree everything cached; returns the bytes given back
+size_t pool_cached_bytes();  // bytes currently kept for reuse (all devices)
 
 // RAII device buffer.
 template <class T>

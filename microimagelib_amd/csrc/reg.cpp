@@ -16,6 +16,37 @@ namespace mil {
 static thread_local int g_last_cost_launches = 0;
 int reg3d_last_cost_launches() { return g_last_cost_launches; }
 
+namespace {
+struct EvalTrace {
+    std::vector<float> rows;  // 13 floats per stored evaluation
+    int capacity = 0, seen = 0;
+};
+thread_local EvalTrace g_trace;
+inline void trace_evaluation(const float *m12, float cost) {
+    EvalTrace &t = g_trace;
+    if (t.capacity <= 0) return;
+    if (t.seen < t.capacity) {
+        t.rows.insert(t.rows.end(), m12, m12 + 12);
+        t.rows.push_back(cost);
+    }
+    ++t.seen;
+}
+}  // namespace
+
+void reg3d_trace_begin(int capacity) {
+    g_trace.rows.clear();
+    g_trace.seen = 0;
+    g_trace.capacity = capacity > 0 ? capacity : 0;
+    if (capacity > 0) g_trace.rows.reserve((size_t)13 * (size_t)capacity);
+}
+
+int reg3d_trace_read(float *out13, int max_entries) {
+    const int stored = (int)(g_trace.rows.size() / 13);
+    const int n = max_entries < stored ? max_entries : stored;
+    if (out13 && n > 0) std::memcpy(out13, g_trace.rows.data(), (size_t)n * 13 * sizeof(float));
+    return g_trace.seen;
+}
+
 // ---------------------------------------------------------------------------
 // matrix parameterisations
 // ---------------------------------------------------------------------------
@@ -474,7 +505,10 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
         ++evals;
         if (!memo_off)
             for (int i = 0; i < memo_n; ++i)
-                if (std::memcmp(memo[i].m, aff.m, sizeof aff.m) == 0) return memo[i].value;
+                if (std::memcmp(memo[i].m, aff.m, sizeof aff.m) == 0) {
+                    trace_evaluation(aff.m, memo[i].value);
+                    return memo[i].value;
+                }
         ++launches;
         double ss = 0, st = 0;
         if (padded) k::corr_sums_padded_sync(tgt_ms.get(), src_pad, dims, aff, corr, stream, &ss, &st);
@@ -485,6 +519,7 @@ int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const fl
         memo[memo_next].value = -zncc;
         memo_next = (memo_next + 1) % kMemo;
         if (memo_n < kMemo) ++memo_n;
+        trace_evaluation(aff.m, -zncc);
         return -zncc;
     };
 

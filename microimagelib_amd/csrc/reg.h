@@ -27,6 +27,12 @@ struct RegOptions {
 // Cost-kernel launches of this thread's last reg3d_affine_device optimisation; records[5] counts cost EVALUATIONS as the
 // reference does, a few per cent of which repeat a point just visited and are answered without a launch.
 int reg3d_last_cost_launches();
+// Test / audit aid: record what this thread's next optimisations evaluate.  capacity > 0 starts a fresh trace of up to that
+// many evaluations (13 floats each: the 12 matrix floats of the reference's global affCoef at that evaluation, then the
+// cost returned to Powell), capacity 0 stops tracing.  reg3d_trace_read copies entries [0, max) and returns how many
+// evaluations were seen (which may exceed the capacity; the surplus is counted, not stored).
+void reg3d_trace_begin(int capacity);
+int reg3d_trace_read(float *out13, int max_entries);
 int reg3d_affine_device(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, Dims dims,
                         int aff_method, bool flag_tmx, float ftol, int it_limit, bool verbose, float *records,
                         hipStream_t stream, const RegOptions &opt = RegOptions());

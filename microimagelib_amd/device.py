@@ -172,6 +172,18 @@ def reg3d_last_cost_launches() -> int:
     return int(_lib.load().mil_reg3d_last_cost_launches())
 
 
+def reg3d_trace_begin(capacity: int) -> None:
+    """Record the (matrix, cost) of every evaluation this thread's next registrations make (0 stops)."""
+    _lib.load().mil_reg3d_trace_begin(int(capacity))
+
+
+def reg3d_trace_read(max_entries: int):
+    """-> (float32 [n][13]: 12 matrix floats + cost per stored evaluation, number of evaluations seen)."""
+    buf = np.zeros((int(max_entries), 13), dtype=np.float32)
+    seen = int(_lib.load().mil_reg3d_trace_read(buf.ctypes.data_as(_lib.c_float_p), int(max_entries)))
+    return buf[:min(seen, int(max_entries))], seen
+
+
 def reg3d_affine(target: torch.Tensor, source: torch.Tensor, aff_method=6, i_tmx=None, flag_tmx=False, ftol=1e-4,
                  it_limit=3000, verbose=False, stream=None):
     """reg3d_affine1 on device-resident volumes.  Returns (registered, tmx[12], records[11])."""

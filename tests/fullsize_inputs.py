@@ -41,6 +41,31 @@ def hash_volume(shape, salt, structure_salt=12345):
     return (np.uint32(100) + noise + amp).astype(np.float32)
 
 
+def displaced_source(shape):
+    """The registration source of the end-to-end fixture (config 4): view 3's noise on the shared brick structure, with
+    the structure sampled at SHEARED and shifted integer coordinates
+
+        x' = x + (y >> 5) - 5,   y' = y - (z >> 4) + 3,   z' = z + (x >> 6) - 2      (clamped to the volume)
+
+    -- a piecewise-integer stand-in for a rotation of a degree or two per axis pair plus a shift, in uint32 arithmetic like
+    everything else here.  The optimum of the target -> source matrix is therefore a genuine 12-parameter matrix
+    (translation about (5, -3, 2), shears 1/32, 1/16, 1/64), which the 3 -> 6 -> 9 -> 12 DOF cascade approaches in stages."""
+    nz, ny, nx = shape
+    z = np.arange(nz, dtype=np.int64)[:, None, None]
+    y = np.arange(ny, dtype=np.int64)[None, :, None]
+    x = np.arange(nx, dtype=np.int64)[None, None, :]
+    xs = np.clip(x + (y >> 5) - 5 + 0 * z, 0, nx - 1).astype(np.uint32)
+    ys = np.clip(y - (z >> 4) + 3 + 0 * x, 0, ny - 1).astype(np.uint32)
+    zs = np.clip(z + (x >> 6) - 2 + 0 * y, 0, nz - 1).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        hb = _mix(((xs >> np.uint32(4)) * np.uint32(73856093)) ^ ((ys >> np.uint32(4)) * np.uint32(19349663)) ^
+                  ((zs >> np.uint32(3)) * np.uint32(83492791)) ^ np.uint32(12345))
+    del xs, ys, zs
+    amp = np.where((hb & np.uint32(7)) == 0, np.uint32(200) + ((hb >> np.uint32(3)) & np.uint32(1023)), np.uint32(0))
+    noise = _lattice(shape, 0, 0, 0, 3) & np.uint32(63)
+    return (np.uint32(100) + noise + amp).astype(np.float32)
+
+
 def binomial_psf(nz, ny, nx):
     """Unnormalised separable PSF of binomial rows C(n-1, k) (n odd -> symmetric about n//2): an integer-valued
     stand-in for a Gaussian of sigma = sqrt(n-1)/2 per axis."""

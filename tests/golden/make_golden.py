@@ -95,6 +95,12 @@ def affine_cases():
     m = ident.copy(); m[3], m[7], m[11] = -0.5, -0.5, -0.5; mats.append(m)              # on the window edge
     mats.append(ro.dof9tomatrix(np.array([0, 1.5, -2.0, 0.5, 3.0, -2.0, 4.0, 1.02, 0.97, 1.05], dtype=f32), 9))
     m = rng.normal(0, 0.02, 12).astype(f32) + ident; m[3], m[7], m[11] = 1.0, 2.0, -1.0; mats.append(m)
+    # rim voxels: texture coordinates t = b + 0.5 in (0, 0.5] on the low faces / in [n - 0.5, n) on the high faces -- inside
+    # the window, interpolating between an edge voxel and its clamped replica (include/cukernel.cuh:545, 515)
+    m = ident.copy(); m[3], m[7], m[11] = -0.25, -0.3, -0.4; mats.append(m)             # low rim: t = 0.25, 0.2, 0.1
+    m = ident.copy(); m[3], m[7], m[11] = 0.25, 0.3, 0.4; mats.append(m)                # high rim: t = n - 0.25 ...
+    m = ident.copy(); m[0], m[5], m[10] = f32(47.5) / f32(47), f32(39.5) / f32(39), f32(23.5) / f32(23)
+    m[3], m[7], m[11] = -0.25, -0.25, -0.25; mats.append(m)                             # both rims at once: b runs -0.25 .. n - 0.75
     mats = np.stack(mats)
     resampled = np.stack([ro.affine_transform(src, m, tgt.shape) for m in mats])
     sums = np.array([ro.corr_sums(tgt, src, m) for m in mats], dtype=np.float64)

@@ -76,3 +76,33 @@ def test_concat_and_fexists(lib, tmp_path):
     assert not lib.fexists(str(f).encode())
     f.write_text("1")
     assert lib.fexists(str(f).encode())
+
+
+def _exported_symbols():
+    import subprocess
+    from microimagelib_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return [line.split()[-1] for line in out.splitlines() if line.strip()]
+
+
+def test_only_the_c_abi_is_exported():
+    """A drop-in library loaded next to torch / ImageJ's JNI glue exports libapi.h + mil_* and nothing else: no C++
+    internals (_ZN3mil...), no HIP fat-binary bookkeeping (csrc/libapi.map)."""
+    syms = _exported_symbols()
+    assert syms, "nm listed no dynamic symbols"
+    mangled = [s for s in syms if s.startswith("_Z")]
+    assert not mangled, mangled[:5]
+    declared = set(declared_functions("libapi.h")) | set(declared_functions("mil_device.h"))
+    extra = [s for s in syms if s not in declared and not s.startswith("mil_")]
+    assert not extra, extra
+    assert declared <= set(syms)
+
+
+def test_profiler_library_is_not_a_link_dependency():
+    """roctx ranges are resolved with dlopen at run time (csrc/trace.h): a ROCm install without rocprofiler-sdk still
+    loads the library."""
+    import subprocess
+    from microimagelib_amd import _lib
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    needed = [line for line in out.splitlines() if "NEEDED" in line]
+    assert needed and not any("roctx" in n or "rocprofiler" in n for n in needed), needed

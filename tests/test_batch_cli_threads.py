@@ -1,0 +1,116 @@
+"""Multi-worker orchestration of the spimFusionBatch tool (microimagelib_amd/cli/spim_fusion_batch_main.cpp) WITHOUT a
+GPU and under ThreadSanitizer: the tool is compiled against host-only stand-ins for the compute entry points
+(tests/stubs/libapi_host_stub.cpp; the TIFF functions are the real csrc/tiff_io.cpp) and must, with 1, 2 and 3 workers,
+write byte-identical stacks, matrix files and projections, a log in time-point order, and trip no data-race report.
+Mirrors the time-point loop and the regMode-2 chain of the reference, src/spim_fusion_batch.cpp:613-966, 786-808.
+The GPU run of the same comparison (two workers on one device) is tests/test_gpu_cli.py."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "build", "tsan")
+
+
+def _write_tiff32(path, vol):
+    """Minimal classic little-endian TIFF stack, one float32 strip per slice (what writetifstack emits)."""
+    vol = np.ascontiguousarray(vol, dtype="<f4")
+    nz, ny, nx = vol.shape
+    n_tags = 9
+    ifd_len = 2 + 12 * n_tags + 4
+    slice_bytes = nx * ny * 4
+    out = bytearray(b"II*\x00" + struct.pack("<I", 8))
+    for z in range(nz):
+        ifd_off = 8 + z * (ifd_len + slice_bytes)
+        data_off = ifd_off + ifd_len
+        tags = [(256, 4, 1, nx), (257, 4, 1, ny), (258, 3, 1, 32), (259, 3, 1, 1), (262, 3, 1, 1), (273, 4, 1, data_off),
+                (277, 3, 1, 1), (279, 4, 1, slice_bytes), (339, 3, 1, 3)]
+        out += struct.pack("<H", n_tags)
+        for tag, typ, cnt, val in tags:
+            out += struct.pack("<HHII", tag, typ, cnt, val)
+        out += struct.pack("<I", 0 if z == nz - 1 else ifd_off + ifd_len + slice_bytes)
+        out += vol[z].tobytes()
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+@pytest.fixture(scope="module")
+def tool():
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "spimFusionBatch_tsan")
+    srcs = [os.path.join(ROOT, "microimagelib_amd", "cli", "spim_fusion_batch_main.cpp"),
+            os.path.join(ROOT, "tests", "stubs", "libapi_host_stub.cpp"),
+            os.path.join(ROOT, "microimagelib_amd", "csrc", "tiff_io.cpp")]
+    newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(ROOT, "microimagelib_amd", "cli", "cli_common.h")])
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", exe] + srcs, check=True,
+                       timeout=600)
+    return exe
+
+
+def _series(tmp_path, n_points):
+    rng = np.random.default_rng(7)
+    os.makedirs(tmp_path / "SPIMA", exist_ok=True)
+    os.makedirs(tmp_path / "SPIMB", exist_ok=True)
+    _write_tiff32(tmp_path / "pa.tif", rng.uniform(0, 1, (3, 3, 3)))
+    _write_tiff32(tmp_path / "pb.tif", rng.uniform(0, 1, (3, 3, 3)))
+    for t in range(n_points):
+        _write_tiff32(tmp_path / "SPIMA" / f"SPIMA_{t}.tif", rng.uniform(10, 500, (6, 10, 12)))
+        _write_tiff32(tmp_path / "SPIMB" / f"SPIMB_{t}.tif", rng.uniform(10, 500, (6, 10, 12)))
+
+
+def _args(tmp_path, out, reg_mode, devices, n_points):
+    return [str(out) + "/", str(tmp_path / "SPIMA") + "/", str(tmp_path / "SPIMB") + "/", "SPIMA_", "SPIMB_", "0",
+            str(n_points - 1), "1", "2", "1", "1", "1", "1", "1", "1", str(reg_mode), "0", "0", "none", "0.001", "150", "0", "1",
+            str(tmp_path / "pa.tif"), str(tmp_path / "pb.tif"), "3", "0", "0", "1", "0", "0", "32", "0", devices]
+
+
+def _tree(root):
+    files = {}
+    for d, _, names in os.walk(root):
+        for n in names:
+            if n != "ProcessingLog.txt":
+                p = os.path.join(d, n)
+                files[os.path.relpath(p, root)] = open(p, "rb").read()
+    return files
+
+
+@pytest.mark.parametrize("reg_mode", [2, 3, 1, 0])
+def test_workers_reproduce_the_single_worker_run(tmp_path, tool, reg_mode):
+    n_points = 7
+    _series(tmp_path, n_points)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    trees = {}
+    for devices in ("0", "0,1", "2,0,1"):
+        out = tmp_path / f"out_{devices.replace(',', '_')}"
+        r = subprocess.run([tool] + _args(tmp_path, out, reg_mode, devices, n_points), capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, (devices, r.stdout[-1500:], r.stderr[-3000:])
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+        trees[devices] = _tree(out)
+        log = open(out / "ProcessingLog.txt").read()
+        seen = [int(line.split(":")[1]) for line in log.splitlines() if line.startswith("*** Image time point number")]
+        want = list(range(n_points))
+        assert seen == ([2] + want if reg_mode == 1 else want), (devices, seen)  # ordered whichever worker finished first
+        assert "Batch processing completed" in log
+    one = trees["0"]
+    assert len(one) == 4 * n_points  # Decon_, Matrix_, MP_XY_ and RegB per time point
+    for devices, t in trees.items():
+        assert set(t) == set(one), devices
+        for name in one:
+            assert t[name] == one[name], (devices, name)
+    if reg_mode == 2:  # the chain really chains: matrices differ from time point to time point
+        mats = [one[os.path.join("TMX", f"Matrix_{t}.tmx")] for t in range(n_points)]
+        assert len(set(mats)) == n_points
+
+
+def test_device_list_from_the_environment(tmp_path, tool):
+    _series(tmp_path, 4)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", MIL_DEVICES="0,0")
+    out = tmp_path / "out_env"
+    r = subprocess.run([tool] + _args(tmp_path, out, 3, "0", 4), capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "2 workers on GPU devices 0,0" in open(out / "ProcessingLog.txt").read()

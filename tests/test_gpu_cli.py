@@ -195,3 +195,29 @@ def test_spimFusionBatch_ours_equals_reference_main(tmp_path, reg_mode):
         assert np.array_equal(mip[0], np.maximum(a.max(axis=0), 0))
         assert os.path.exists(outs["ours"] / "RegB" / f"SPIMB_reg_{t}.tif")
     assert "Image time point number" in open(outs["ours"] / "ProcessingLog.txt").read()
+
+
+@pytest.mark.parametrize("reg_mode", [2, 3])
+def test_spimFusionBatch_two_workers_on_one_device(tmp_path, reg_mode):
+    """one host worker thread per listed device.  Two workers sharing device 0 (the only way to
+    run the multi-device code on a one-GPU box: separate threads, engines, OTFs, streams and buffers inside libapi.so)
+    reproduce the single-worker stacks, matrix files and projections bit for bit -- in the chained mode too, where the
+    chain state is handed from worker to worker (src/spim_fusion_batch.cpp:786-808)."""
+    exe = _need("spimFusionBatch", "ours")
+    _make_series(tmp_path)
+    outs = {}
+    for name, devices in (("one", "0"), ("two", "0,0")):
+        out = tmp_path / f"out_{name}"
+        args = _batch_args(tmp_path, out, reg_mode)
+        args[-1] = devices
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = out
+    assert "2 workers on GPU devices 0,0" in open(outs["two"] / "ProcessingLog.txt").read()
+    for sub, names in (("Decon", [f"Decon_{t}.tif" for t in range(3)]), ("TMX", [f"Matrix_{t}.tmx" for t in range(3)]),
+                       (os.path.join("Decon", "MP_ZProj"), [f"MP_XY_{t}.tif" for t in range(3)]),
+                       ("RegB", [f"SPIMB_reg_{t}.tif" for t in range(3)])):
+        for n in names:
+            a = open(outs["one"] / sub / n, "rb").read()
+            b = open(outs["two"] / sub / n, "rb").read()
+            assert a == b, (sub, n)

@@ -153,6 +153,43 @@ def test_cached_calls_are_bit_identical(api, monkeypatch):
     assert api.release_cached_memory() >= 0
 
 
+def test_concurrent_host_threads_get_the_serial_bits(api):
+    """Several host threads inside one process, as a multi-GPU host of the reference would drive it (deviceNum per
+    thread): each call checks out its own engine + OTFs (csrc/api_decon.cpp, DeconCache::checkout), nothing is shared
+    but the device pool.  Three boxes, six threads, repeated: every result equals the serial call bit for bit -- also
+    when more boxes are in flight than the cache keeps per device, and while the cache is being dropped."""
+    import threading
+    g = np.load(os.path.join(GOLD, "decon_sv_small.npz"))
+    d = np.load(os.path.join(GOLD, "decon_dv_small.npz"))
+    big = np.load(os.path.join(GOLD, "decon_sv_psf_eq_fft.npz"))
+    jobs = {
+        "sv": lambda: api.decon_singleview(g["img"], g["psf"], int(g["iters"]))[0],
+        "dv": lambda: api.decon_dualview(d["img1"], d["img2"], d["psf1"], d["psf2"], int(d["iters"]))[0],
+        "big": lambda: api.decon_singleview(big["img"], big["psf"], int(big["iters"]))[0],
+    }
+    api.release_cached_memory()
+    serial = {k: f() for k, f in jobs.items()}
+    results, errors = {}, []
+
+    def run(tag, key, rounds):
+        try:
+            for r in range(rounds):
+                results[(tag, r)] = (key, jobs[key]())
+        except Exception as e:  # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(i, key, 3)) for i, key in enumerate(["sv", "dv", "big", "sv", "big", "dv"])]
+    for t in threads:
+        t.start()
+    api.release_cached_memory()  # drops idle entries only; busy ones finish their call
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 18
+    for (tag, r), (key, out) in results.items():
+        assert np.array_equal(out.view(np.uint32), serial[key].view(np.uint32)), (tag, r, key)
+
+
 def test_memory_mode_2_runs_as_mode_1(api):
     g = np.load(os.path.join(GOLD, "decon_sv_psf_eq_fft.npz"))
     out, rec = api.decon_singleview(g["img"], g["psf"], 2, gpu_mem_mode=2)

@@ -163,7 +163,8 @@ def test_mip3d_matches_oracle(api):
         for i in range(6):
             m = ro.rot2matrix(f32(step * f32(i)), sx, sy, sz, axis)
             want = np.maximum(ro.affine_transform(vol, m, box).max(axis=0), f32(0))
-            assert np.max(np.abs(got[i] - want)) <= 1e-4 * vol.max(), f"axis {axis} angle {i}"
+            # rot2matrix is pinned bit for bit, the resample is bit-exact and a maximum is exact: so is the projection
+            assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), f"axis {axis} angle {i}"
 
 
 # ---------------------------------------------------------------- regChoice 4: 2-D MIP shift search
@@ -306,6 +307,43 @@ def test_full_size_cost_and_resample_vs_oracle_fixture(dev, api):
     ss0, st0 = g["corr_sums"][0]
     want = f32(f32(st0 / np.sqrt(ss0)) / f32(np.sqrt(float(g["tgt_sumsq"]))))
     assert abs(rec[1] - want) <= 2e-7 * abs(want), (rec[1], want)
+
+
+@pytest.mark.parametrize("fixture", ["fullsize_reg_traj.npz", "fullsize_reg_traj_full.npz"])
+def test_full_size_registration_trajectory_vs_oracle_fixture(dev, fixture):
+    """BASELINE.json config 4 END TO END at 512 x 512 x 256: reg3d_affine1's 3 -> 6 -> 9 -> 12 DOF cascade
+    (src/api_subfunc.cu:2889-2957, affMethod 7) on the closed-form sheared pair of tests/fullsize_inputs.py.  The oracle
+    (its driver + the reference's compiled powell(), every cost evaluated by the NumPy restatement of corrkernel) recorded
+    every matrix it evaluated and the cost it saw (tests/golden/make_golden_fullsize.py traj / trajfull); the HIP path
+    must visit the SAME matrices bit for bit, see the same costs to 1e-6, stop after the same number of evaluations and
+    hand back the same matrix and records.  itLimit 40 (the stages hand over after their first line minimisations) and
+    the cascade run to convergence."""
+    import torch
+    from tests import fullsize_inputs as fi
+    path = os.path.join(GOLD, fixture)
+    if not os.path.exists(path):
+        pytest.skip(f"{fixture} not generated")
+    g = np.load(path)
+    shape = fi.FULL_SHAPE
+    tgt, src = T(fi.hash_volume(shape, 1)), T(fi.displaced_source(shape))
+    want = g["trace"]
+    dev.reg3d_trace_begin(len(want) + 16)
+    reg, tmx, rec = dev.reg3d_affine(tgt, src, aff_method=int(g["aff_method"]), ftol=1e-4, it_limit=int(g["it_limit"]))
+    got, seen = dev.reg3d_trace_read(len(want) + 16)
+    dev.reg3d_trace_begin(0)
+    assert seen == len(want), (seen, len(want))
+    same = np.all(got[:, :12].view(np.uint32) == want[:, :12].view(np.uint32), axis=1)
+    assert same.all(), f"first differing evaluation: {int(np.argmin(same))} of {len(want)}"
+    assert np.max(np.abs(got[:, 12].astype(np.float64) - want[:, 12])) <= 1e-6
+    assert np.array_equal(tmx.view(np.uint32), g["tmx"].view(np.uint32))
+    w_rec = g["records"]
+    assert rec[5] == w_rec[5] == len(want) - 1  # evaluations after the initial one (src/api_subfunc.cu:2888)
+    for i in (1, 2, 3):
+        assert abs(float(rec[i]) - float(w_rec[i])) <= 1e-6, (i, rec[i], w_rec[i])
+    idx = torch.from_numpy(fi.sample_indices(int(np.prod(shape)))).cuda()
+    assert np.array_equal(reg.reshape(-1)[idx].cpu().numpy().view(np.uint32), g["reg_samples"].view(np.uint32))
+    planes = reg.double().sum(dim=(1, 2)).cpu().numpy()
+    assert np.all(np.abs(planes - g["reg_planes"]) <= 1e-12 * np.maximum(np.abs(g["reg_planes"]), 1.0))
 
 
 def test_registration_orders_itself_after_pending_stream_work(dev):
