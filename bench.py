@@ -120,6 +120,9 @@ def main():
     # functional test of the N > 1 path on a one-GPU box: all ranks on cuda:0, collectives over gloo (never a measurement)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
+    # run the collective code (barrier, all-reduce of the time, MIP gather) even in a world of ONE rank: the only way to
+    # execute the RCCL branch on a one-GPU box (RCCL refuses two ranks on one device, profiles/r03/nccl_two_ranks_one_gpu.txt)
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["auto", "rocfft", "fused"], default="auto",
                     help="transform backend of the RL engine (auto = fused LDS-tiled kernels on power-of-two boxes)")
     args = ap.parse_args()
@@ -137,10 +140,11 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the (tiny) collective payloads live
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:

@@ -152,8 +152,13 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
     sink(t, decon, tmx, reg_records) persists per-time-point outputs (rank-local, no exchange).
     overlap: deconvolution + sink of time point i run on a helper thread while this thread registers time point i + 1
     (independent streams on the GPU: the deconvolution fills the gaps between Powell's cost evaluations), and
-    load_pair(i + 2) runs on a second helper thread (file decode + upload hidden behind the registration; load_pair must
-    hand out buffers that stay valid for two calls).  Results are the same, only the order of host-side side effects
+    load_pair(i + 2) runs on a second helper thread (file decode + upload hidden behind the registration).  BUFFER
+    CONTRACT with overlap: THREE pairs are live at once -- the pair of time point i is still being read by the
+    deconvolution worker while the pair of i + 1 is registered and load_pair(i + 2) is already filling its buffers -- so
+    load_pair must hand out buffers that stay valid for the next TWO calls (rotate at least three sets, or allocate), and
+    reg_fn must return a registered volume that does not alias the one it returned for the previous time point (the worker
+    reads b_reg of i while i + 1 is registered).  fuse_pair may reuse one output buffer: one deconvolution is in flight at
+    a time and its MIP is cloned before the next starts.  Results are the same, only the order of host-side side effects
     within a rank changes.  Modes 0, 1, 3.
     Returns the time-ordered MIP stack on rank 0."""
     rank, world = _world(group)

@@ -42,6 +42,7 @@ struct PaddedArgs {
     int row4;             // padded row pitch in bytes, 4 * (sx + 2)
     int plane4;           // padded plane pitch in bytes
     int origin4;          // byte offset of source voxel (0, 0, 0) inside the padded volume
+    int origin4m;         // the same with the constants of the two-voxel kernels' bit-pattern index arithmetic folded in
     unsigned bytes;       // size of the padded volume
     int gx, gy;           // tiles along x and y of the launched kernel (grid = gx * gy * gz workgroups, one-dimensional)
 };
@@ -321,11 +322,9 @@ __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__r
 // use -- a wave here covers two of their waves, a workgroup two of their workgroups, published separately
 // (corr_publish_as) -- so every cost kernel returns the same bits.
 template <bool PAIRS, bool REUSE>
-__global__ __launch_bounds__(kThreads) void corr_pair_kernel(const float *__restrict__ tgt,
-                                                           const float *__restrict__ srcp, PaddedArgs a,
-                                                           CorrTail tail, int old_grid_x) {
-    __shared__ double lds[4 * kTileY];
-    __shared__ int last;
+__device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, const float *__restrict__ srcp,
+                                               const PaddedArgs &a, const CorrTail &tail, int old_grid_x, double *lds,
+                                               int *last_p) {
     const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
     int bx, by, bz;
     corr_tile_of_block(a.gx, a.gy, bx, by, bz);
@@ -397,9 +396,23 @@ __global__ __launch_bounds__(kThreads) void corr_pair_kernel(const float *__rest
             B.wy.y = BY.y - fyB; B.wy.x = 1.0f - B.wy.y;
             B.wz.y = BZ.y - fzB; B.wz.x = 1.0f - B.wz.y;
             constexpr int SH = PAIRS ? 3 : 2;
-            // nested multiply-adds (v_mad_i32_i24): off = fz * plane + (fy * row + ((fx << SH) + origin))
-            A.off = (unsigned)(__mul24((int)fzA, a.plane4) + (__mul24((int)fyA, a.row4) + (((int)fxA << SH) + a.origin4)));
-            B.off = (unsigned)(__mul24((int)fzB, a.plane4) + (__mul24((int)fyB, a.row4) + (((int)fxB << SH) + a.origin4)));
+            {
+                // Index arithmetic without float -> int conversions: f + 1.5 * 2^23 is exact for the integer f (|f| < 2^22)
+                // and its bit pattern is 0x4B400000 + f, so the LOW 24 BITS are 2^22 + f -- exactly what the 24-bit
+                // multiply-adds read.  One packed add serves both voxels; the constant parts (2^22 * pitch, the shifted
+                // exponent bits) are folded into `origin4m` by the host (modulo 2^32, like every step of this sum).  A lane
+                // outside the window gets a meaningless offset here -- and never uses it (CHECK path below).
+                const f32x2 magic = {12582912.0f, 12582912.0f};
+                const f32x2 MX = (f32x2){fxA, fxB} + magic, MY = (f32x2){fyA, fyB} + magic, MZ = (f32x2){fzA, fzB} + magic;
+                auto mad24 = [](unsigned x, unsigned y, unsigned z) {
+                    unsigned r;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(y), "v"(z));
+                    return r;
+                };
+                const unsigned row = (unsigned)a.row4, plane = (unsigned)a.plane4, org = (unsigned)a.origin4m;
+                A.off = mad24(__float_as_uint(MZ.x), plane, mad24(__float_as_uint(MY.x), row, (__float_as_uint(MX.x) << SH) + org));
+                B.off = mad24(__float_as_uint(MZ.y), plane, mad24(__float_as_uint(MY.y), row, (__float_as_uint(MX.y) << SH) + org));
+            }
             if (CHECK) {
                 A.off = A.in ? A.off : 0u;
                 B.off = B.in ? B.off : 0u;
@@ -564,8 +577,17 @@ __global__ __launch_bounds__(kThreads) void corr_pair_kernel(const float *__rest
     for (int h = 0; h < 2; ++h) {
         const int obx = 2 * bx + h;  // workgroup x index of the 64-wide decomposition
         if (obx < old_grid_x)
-            corr_publish_as<kThreads>(obx + old_grid_x * (by + a.gy * bz), v0[h], v1[h], tail, lds, &last);
+            corr_publish_as<kThreads>(obx + old_grid_x * (by + a.gy * bz), v0[h], v1[h], tail, lds, last_p);
     }
+}
+
+template <bool PAIRS, bool REUSE>
+__global__ __launch_bounds__(kThreads) void corr_pair_kernel(const float *__restrict__ tgt,
+                                                           const float *__restrict__ srcp, PaddedArgs a,
+                                                           CorrTail tail, int old_grid_x) {
+    __shared__ double lds[4 * kTileY];
+    __shared__ int last;
+    corr_pair_body<PAIRS, REUSE>(tgt, srcp, a, tail, old_grid_x, lds, &last);
 }
 
 // dst[z+1][y+1][x+1] = (src[z][y][x], src[z][y+1][x]) with edge replication; y runs over [-1, sy-1].
@@ -669,6 +691,15 @@ int pick_kernel(const float *m, bool has_pairs, bool wide) {
     return layout + ((wide && layout != 1) ? 3 : 0);
 }
 
+// The two-voxel kernels form their indices from the bit patterns of floor + 1.5 * 2^23 (corr_pair_kernel, prepare): the
+// 24-bit multiplies then see 2^22 + f, the shift sees 0x4B400000 + f.  What that adds to the sum is a constant; it goes into
+// the origin here, modulo 2^32.
+int magic_origin(int origin4, int row4, int plane4, int shift) {
+    const unsigned bias24 = 0x400000u, bits = 0x4B400000u;
+    const unsigned k = bias24 * (unsigned)plane4 + bias24 * (unsigned)row4 + (bits << shift);
+    return (int)((unsigned)origin4 - k);
+}
+
 }  // namespace
 
 void corr_padded_force_kernel(int kernel) { g_forced_kernel = kernel; }
@@ -689,7 +720,8 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
     // the partials are those of the 64 x 4 x 16 decomposition whichever kernel runs
     const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
     // two voxels per lane (x and x + 64): whole 128-wide workgroups only
-    const bool wide = a.tx % (2 * kTileX) == 0;
+    // ... and source extents the bit-pattern index arithmetic of corr_pair_kernel holds exactly (|index| < 2^22)
+    const bool wide = a.tx % (2 * kTileX) == 0 && xp < (1 << 22) && yp < (1 << 22) && zp < (1 << 22);
     const int kernel = pick_kernel(a.m, src.has_pairs, wide);
     const int layout = kernel % 3;
     const int old_gx = (int)grid.x;
@@ -705,6 +737,7 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
         a.origin4 = (int)(8 * ((yp2 + 1) * xp + 1));
         a.bytes = (unsigned)(8 * xp * yp2 * zp);
         const float *p = src.pairs.get();
+        a.origin4m = magic_origin(a.origin4, a.row4, a.plane4, 3);
         switch (kernel) {
             case 1: hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, p, a, tail); break;
             case 2: hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, p, a, tail); break;
@@ -717,6 +750,7 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
         a.plane4 = (int)(4 * pitch * yp);
         a.origin4 = (int)(4 * (pitch * yp + pitch + 1));
         a.bytes = (unsigned)(4 * pitch * yp * zp);
+        a.origin4m = magic_origin(a.origin4, a.row4, a.plane4, 2);
         if (kernel == 3)
             hipLaunchKernelGGL((corr_pair_kernel<false, true>), grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail, old_gx);
         else

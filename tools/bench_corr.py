@@ -39,4 +39,4 @@ for name, m in cases:
         r = mdev.corr_sums(tgt, source, m)
     dt = (time.perf_counter() - t0) / n
     vox = tgt.numel()
-    print(f"{name:12s} {dt*1e3:8.3f} ms/eval  {vox/dt/1e9:8.1f} Gvoxel/s  {2*4*vox/dt/1e9:8.1f} GB/s algorithmic  ss={ss:.6e} st={st:.6e}")
+    print(f"{name:12s} {dt*1e3:8.3f} ms/eval  {vox/dt/1e9:8.1f} Gvoxel/s  {2*4*vox/dt/1e9:8.1f} GB/s algorithmic  ss={float(ss).hex()} st={float(st).hex()}")
