@@ -46,7 +46,7 @@ def tool():
             os.path.join(ROOT, "microimagelib_amd", "csrc", "tiff_io.cpp")]
     newest = max(os.path.getmtime(s) for s in srcs + [os.path.join(ROOT, "microimagelib_amd", "cli", "cli_common.h")])
     if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
-        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", exe] + srcs, check=True,
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", exe] + srcs + ["-lz"], check=True,
                        timeout=600)
     return exe
 
