@@ -8,10 +8,14 @@
 //   yz_conv_kernel   8 adjacent rows x 16 columns x all z per workgroup:  y stage(8) . z . OTF . z^-1 . y stage(8)^-1
 //   xy_kernel        the 64 rows y = n2 + 8m of one z plane per workgroup:  y head^-1 . x^-1 . op . x . y head
 //
-// Both tiles (256 KB / 128 KB) are larger than the LDS, so they live in REGISTERS (64 complex per thread); LDS only
-// carries the exchanges between "all z of one (row, column)" and "all rows of one (z, column)" ownership.  Positions,
+// Both tiles (256 KB / 128 KB at nz = 256) are larger than the LDS, so they live in REGISTERS (64 complex per thread); LDS
+// only carries the exchanges between "all z of one (row, column)" and "all rows of one (z, column)" ownership.  Positions,
 // twiddles and the OTF tiling are exactly those of the classic kernels (same in-place digit-reversed order), so both
 // paths share OTFs and can be mixed stage by stage (MIL_FX_TWOPASS, tests/test_gpu_fft.py).
+//
+// Boxes: 512 x 512 in x and y (the xy kernel holds the 64 rows y = n2 + 8m of one plane per thread and one column per
+// thread; it does not care about z), z = 256 (register yz kernel) or z = 128 / 64, where the yz tile (8 rows x 16 columns
+// x all z = 128 / 64 KB) FITS the LDS and yz_lds_kernel runs the same sequence with the classic LDS stage code.
 #include "fftconv.h"
 
 #include <cstdlib>
@@ -24,7 +28,7 @@ namespace {
 
 #include "fft_dev.h"
 
-constexpr int kNY = 512, kNZ = 256, kNH = 256;  // the box this path is built for: 512 x 512 x 256 (x, y, z)
+constexpr int kNY = 512, kNZ = 256, kNH = 256;  // x and y extents of every box of this path; kNZ: the register yz kernel's z
 constexpr int kPitch = 272;                      // spectrum row pitch (ConvPlan: columns + 16)
 constexpr int kGroups = kNH / kW;                // 16-column groups per row
 
@@ -50,9 +54,8 @@ __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned vo
 __constant__ float2 c_tw_y[kNY];
 __constant__ float2 c_tw_z[kNZ];
 
-constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8;
+constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8;  // register yz kernel (nz = 256)
 constexpr long long kOtfBytes = (long long)kNH * kNY * kNZ * 8;
-constexpr long long kRealBytes = 2LL * kNH * kNY * kNZ * 4;
 
 // ---------------------------------------------------------------------------
 // partial y passes (classic column tiles): head = the stages of length > 8, tail = the stage of length 8
@@ -120,6 +123,69 @@ __device__ __forceinline__ float2 swap_pair(float2 a) {
     const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
     const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a.y), 0xB1, 0xF, 0xF, false);
     return make_float2(__int_as_float(x), __int_as_float(y));
+}
+
+// ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
+// One workgroup per pair of row blocks, 2 x 8 rows x NZ z of column 0 in LDS as tile[z][17].  `tw`: w_NZ^k, any address
+// space the 512 threads may index freely.
+template <int NZ>
+__device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *tile, const float2 *tw, int pair) {
+    const int tid = threadIdx.x;
+    const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
+    for (int i = tid; i < NZ * 16; i += kYzThreads) {
+        const int c = i & 15, z = i >> 4;
+        tile[z * kWP + c] = a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch];
+    }
+    lds_barrier();
+    for (int i = tid; i < NZ * 2; i += kYzThreads) {
+        float2 *p = tile + (i >> 1) * kWP + 8 * (i & 1);
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = p[k];
+        dft8<-1>(t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = t[k];
+    }
+    lds_barrier();
+    fft_dif<NZ, NZ, -1, kW, kYzThreads, kWP>(tile, tw);
+    constexpr int PER = (NZ * 16 + kYzThreads - 1) / kYzThreads;
+    float2 r[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = i * kYzThreads + tid, c = e & 15, p = e >> 4;
+        if (e < NZ * 16) {
+            const int row = 8 * blk[c >> 3] + (c & 7);
+            const int prow = a.neg_y[row];
+            const int pc = ((prow >> 3) == blk[0] ? 0 : 8) + (prow & 7);
+            const float2 gk = tile[p * kWP + c], gp = tile[a.neg_z[p] * kWP + pc];
+            const float2 pv = a.otf[(((long long)row * kGroups) * NZ + p) * kW];
+            const float2 qv = a.otf_q[(long long)row * NZ + p];
+            r[i] = c_add(c_mul(gk, pv), c_mul(qv, make_float2(gp.x, -gp.y)));
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = i * kYzThreads + tid;
+        if (e < NZ * 16) tile[(e >> 4) * kWP + (e & 15)] = r[i];
+    }
+    lds_barrier();
+    fft_dit<NZ, NZ, +1, kW, kYzThreads>(tile, tw);
+    for (int i = tid; i < NZ * 2; i += kYzThreads) {
+        float2 *p = tile + (i >> 1) * kWP + 8 * (i & 1);
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = p[k];
+        dft8<+1>(t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] = t[k];
+    }
+    lds_barrier();
+    const int ncol = (blk[0] == blk[1]) ? 8 : 16;
+    for (int i = tid; i < NZ * 16; i += kYzThreads) {
+        const int c = i & 15, z = i >> 4;
+        if (c < ncol) a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch] = tile[z * kWP + c];
+    }
 }
 
 __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
@@ -305,63 +371,116 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
 #endif
         return;
     }
-    // ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
-    // One workgroup per pair of row blocks, 2 x 8 rows x 256 z of column 0 in LDS as tile[z][17].
+    packed_column_block<kNZ>(a, lds, twz, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// yz_conv for z <= 128: the 8 rows x 16 columns x NZ tile fits the LDS (NZ KB + padding), so the same sequence
+//   y stage(8) . z . OTF . z^-1 . y stage(8)^-1
+// runs on tile[z][8 rows x 16 columns] with the classic LDS stage code, 128 "columns" per z position.  One trip of the
+// spectrum through HBM (3 C'') where the classic kernels make three (y tail | z-conv | y tail^-1: 7 C'').
+// ---------------------------------------------------------------------------
+template <int NZ, int COLS>
+__global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
+    // COLS = 16: 128-byte row segments, tile = NZ KB; COLS = 8: 64-byte segments, half the tile -- two workgroups per CU
+    // at NZ = 128, whose load / transform / store phases then overlap
+    constexpr int W = 8 * COLS, WP = W + 1;  // row r, column c of the block sit at "column" r * COLS + c
+    constexpr int QR = COLS / 2;             // float4 pieces per row segment
+    __shared__ float2 tile[NZ * WP > NZ * kWP ? NZ * WP : NZ * kWP];
+    __shared__ float2 tw[NZ];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < NZ; k += kYzThreads) tw[k] = tw_z[k];
+    if ((int)blockIdx.x < a.pair_blocks) {
+        lds_barrier();
+        packed_column_block<NZ>(a, tile, tw, (int)blockIdx.x);
+        return;
+    }
+    constexpr int GROUPS = kNH / COLS;
+    const int tile_id = blockIdx.x - a.pair_blocks;
+    const int g = tile_id % GROUPS, b = tile_id / GROUPS;
+    const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // the 16-column group of the OTF tiling, offset inside it
+    float2 *base = a.S + (long long)(8 * b) * kPitch + g * COLS;
+    constexpr long long zstride = (long long)kNY * kPitch;
+    // ---- load: NZ x 8 row segments
+    constexpr int TOTAL = NZ * 8 * QR;  // float4 pieces
+#pragma unroll 1
+    for (int it0 = 0; it0 < TOTAL; it0 += kYzThreads * kBatch) {
+        float4 v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = it0 + j * kYzThreads + tid;
+            const int q = idx % QR, row = (idx / QR) & 7, z = idx / (8 * QR);
+            if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(base + z * zstride + (long long)row * kPitch + 2 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = it0 + j * kYzThreads + tid;
+            const int q = idx % QR, row = (idx / QR) & 7, z = idx / (8 * QR);
+            if (idx < TOTAL) {
+                float2 *p = tile + z * WP + row * COLS + 2 * q;
+                p[0] = make_float2(v[j].x, v[j].y);
+                p[1] = make_float2(v[j].z, v[j].w);
+            }
+        }
+    }
+    lds_barrier();
+    // ---- y stage of length 8 over the rows of every (z, column)
+    for (int i = tid; i < NZ * COLS; i += kYzThreads) {
+        float2 *p = tile + (i / COLS) * WP + (i % COLS);
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = p[k * COLS];
+        dft8<-1>(t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k * COLS] = t[k];
+    }
+    lds_barrier();
+    fft_dif<NZ, NZ, -1, W, kYzThreads, WP>(tile, tw);
+    // ---- OTF product: the classic tiling [row][16-column group][kz][16]
     {
-        float2 *tile = lds;
-        const int pair = blockIdx.x;
-        const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
-        for (int i = tid; i < kNZ * 16; i += kYzThreads) {
-            const int c = i & 15, z = i >> 4;
-            tile[z * kWP + c] = a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch];
-        }
-        lds_barrier();
-        {
-            float2 *p = tile + (tid >> 1) * kWP + 8 * (tid & 1);
-            float2 t[8];
+        constexpr int PIECES = 8 * NZ * QR;  // float4 pieces
+#pragma unroll 1
+        for (int it0 = 0; it0 < PIECES; it0 += kYzThreads * kBatch) {
+            float4 v[kBatch];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = p[k];
-            dft8<-1>(t);
+            for (int j = 0; j < kBatch; ++j) {
+                const int idx = it0 + j * kYzThreads + tid;
+                const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
+                if (idx < PIECES)
+                    v[j] = *reinterpret_cast<const float4 *>(a.otf + ((((long long)(8 * b + row) * kGroups + g16) * NZ + kz) * kW) + c16 + 2 * q);
+            }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) p[k] = t[k];
+            for (int j = 0; j < kBatch; ++j) {
+                const int idx = it0 + j * kYzThreads + tid;
+                const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
+                if (idx < PIECES) {
+                    float2 *p = tile + kz * WP + row * COLS + 2 * q;
+                    p[0] = c_mul(p[0], make_float2(v[j].x, v[j].y));
+                    p[1] = c_mul(p[1], make_float2(v[j].z, v[j].w));
+                }
+            }
         }
-        lds_barrier();
-        fft_dif<kNZ, kNZ, -1, kW, kYzThreads, kWP>(tile, twz);
-        float2 r[8];
+    }
+    lds_barrier();
+    fft_dit<NZ, NZ, +1, W, kYzThreads>(tile, tw);
+    for (int i = tid; i < NZ * COLS; i += kYzThreads) {
+        float2 *p = tile + (i / COLS) * WP + (i % COLS);
+        float2 t[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = i * kYzThreads + tid, c = e & 15, p = e >> 4;
-            const int row = 8 * blk[c >> 3] + (c & 7);
-            const int prow = a.neg_y[row];
-            const int pc = ((prow >> 3) == blk[0] ? 0 : 8) + (prow & 7);
-            const float2 gk = tile[p * kWP + c], gp = tile[a.neg_z[p] * kWP + pc];
-            const float2 pv = a.otf[(((long long)row * kGroups) * kNZ + p) * kW];
-            const float2 qv = a.otf_q[(long long)row * kNZ + p];
-            r[i] = c_add(c_mul(gk, pv), c_mul(qv, make_float2(gp.x, -gp.y)));
-        }
-        lds_barrier();
+        for (int k = 0; k < 8; ++k) t[k] = p[k * COLS];
+        dft8<+1>(t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = i * kYzThreads + tid;
-            tile[(e >> 4) * kWP + (e & 15)] = r[i];
-        }
-        lds_barrier();
-        fft_dit<kNZ, kNZ, +1, kW, kYzThreads>(tile, twz);
-        {
-            float2 *p = tile + (tid >> 1) * kWP + 8 * (tid & 1);
-            float2 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = p[k];
-            dft8<+1>(t);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) p[k] = t[k];
-        }
-        lds_barrier();
-        const int ncol = (blk[0] == blk[1]) ? 8 : 16;
-        for (int i = tid; i < kNZ * 16; i += kYzThreads) {
-            const int c = i & 15, z = i >> 4;
-            if (c < ncol) a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch] = tile[z * kWP + c];
-        }
+        for (int k = 0; k < 8; ++k) p[k * COLS] = t[k];
+    }
+    lds_barrier();
+    // ---- store; the packed column (group 0, column 0) belongs to the pair blocks
+#pragma unroll 4
+    for (int idx = tid; idx < TOTAL; idx += kYzThreads) {
+        const int q = idx % QR, row = (idx / QR) & 7, z = idx / (8 * QR);
+        const float2 *p = tile + z * WP + row * COLS + 2 * q;
+        float2 *dst = base + z * zstride + (long long)row * kPitch + 2 * q;
+        if (g == 0 && q == 0) dst[1] = p[1];
+        else *reinterpret_cast<float4 *>(dst) = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
     }
 }
 
@@ -375,6 +494,7 @@ struct XyArgs {
     const float *M;  // measured image, ratio mode
     const float2 *tw_x;
     float eps;
+    long long spec_bytes, real_bytes;  // extents of S and of the real volumes (buffer descriptors)
     unsigned long long *stamps;  // timing experiments: 8 wall-clock stamps (100 MHz) per workgroup, or null
 };
 
@@ -400,8 +520,8 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     const int ez = tid == 1 ? kNH / 2 : (odd ? kNH - kc : kc);
     const int pz = 16 * (ez & 15) + (ez >> 4);
     const int pzs = pz * WP + (pz >> 4);  // its place in the skewed tile
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes);
-    const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, kRealBytes);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, a.spec_bytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, a.real_bytes);
     const unsigned voff = (unsigned)tid * 8u;
     const unsigned soff0 = (unsigned)((z * kNY + n2) * kPitch) * 8u;  // + m * rstep
     constexpr unsigned rstep = 8u * kPitch * 8u;
@@ -575,7 +695,9 @@ unsigned long long *g_stamps = nullptr;  // set through mil_fx_set_stamps (timin
 
 }  // namespace
 
-bool ConvPlan::two_pass_supported(Dims b) { return b.nx == 2 * kNH && b.ny == kNY && b.nz == kNZ; }
+bool ConvPlan::two_pass_supported(Dims b) {
+    return b.nx == 2 * kNH && b.ny == kNY && (b.nz == kNZ || b.nz == 128 || b.nz == 64);
+}
 
 void ConvPlan::init_two_pass() {
     if (!two_pass_supported(box_) || pitch_ != kPitch) return;
@@ -593,11 +715,14 @@ void ConvPlan::init_two_pass() {
         }
     }
     {
-        std::vector<float2> ty((size_t)kNY), tz((size_t)kNZ);
+        std::vector<float2> ty((size_t)kNY);
         MIL_HIP(hipMemcpy(ty.data(), tw_y_.get(), ty.size() * sizeof(float2), hipMemcpyDeviceToHost));
-        MIL_HIP(hipMemcpy(tz.data(), tw_z_.get(), tz.size() * sizeof(float2), hipMemcpyDeviceToHost));
         MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_y), ty.data(), ty.size() * sizeof(float2)));
-        MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_z), tz.data(), tz.size() * sizeof(float2)));
+        if (box_.nz == kNZ) {  // the register yz kernel reads its z twiddles from constant memory
+            std::vector<float2> tz((size_t)kNZ);
+            MIL_HIP(hipMemcpy(tz.data(), tw_z_.get(), tz.size() * sizeof(float2), hipMemcpyDeviceToHost));
+            MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_z), tz.data(), tz.size() * sizeof(float2)));
+        }
     }
     n_pairs_ = (int)pairs.size() / 2;
     pairs_.alloc(pairs.size());
@@ -628,7 +753,12 @@ void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     a.neg_y = neg_y_.get(); a.neg_z = neg_z_.get(); a.pairs = pairs_.get();
     a.pair_blocks = n_pairs_;
     a.stamps = g_stamps;
-    hipLaunchKernelGGL(yz_conv_kernel, dim3((unsigned)((kNY / 8) * kGroups + n_pairs_)), dim3(kYzThreads), 0, s, a);
+    const dim3 grid((unsigned)((kNY / 8) * kGroups + n_pairs_));
+    // (8-column tiles -- 64-byte segments, two workgroups per CU at nz = 128 -- measured: 2 200 against 2 170 it/s, within
+    // noise, profiles/r03/bench_box_nz128.txt; the 16-column form stays)
+    if (box_.nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel, grid, dim3(kYzThreads), 0, s, a);
+    else if (box_.nz == 128) hipLaunchKernelGGL((yz_lds_kernel<128, 16>), grid, dim3(kYzThreads), 0, s, a, (const float2 *)tw_z_.get());
+    else hipLaunchKernelGGL((yz_lds_kernel<64, 16>), grid, dim3(kYzThreads), 0, s, a, (const float2 *)tw_z_.get());
     MIL_HIP(hipGetLastError());
 }
 
@@ -637,8 +767,10 @@ void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float ep
     if (!S || (mode == kXRatio ? !M : !E)) throw Error(-1, "xy_pass: missing operand");
     XyArgs a;
     a.S = S; a.E = E; a.M = M; a.tw_x = tw_x_.get(); a.eps = eps;
+    a.spec_bytes = (long long)kPitch * kNY * box_.nz * 8;
+    a.real_bytes = 2LL * kNH * kNY * box_.nz * 4;
     a.stamps = (g_stamps && mode == kXRatio) ? g_stamps + 2048 * 16 : nullptr;
-    const dim3 grid((unsigned)(kNZ * 8)), block(kNT);
+    const dim3 grid((unsigned)(box_.nz * 8)), block(kNT);
     switch (mode) {
         case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio>), grid, block, 0, s, a); break;
         case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate>), grid, block, 0, s, a); break;

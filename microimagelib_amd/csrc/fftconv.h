@@ -58,7 +58,7 @@ public:
     // test aid: private OTF order -> natural [nz][ny][nx/2+1] (rocFFT / numpy rfftn order)
     void otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const;
 
-    // ---- two-pass path (csrc/fft2p.hip; 512 x 512 x 256 boxes): the last radix-8 stage of the y transform rides in the
+    // ---- two-pass path (csrc/fft2p.hip; 512 x 512 x {256, 128, 64} boxes): the last radix-8 stage of the y transform rides in the
     // z kernel and its first two in the x kernel, so a half view update is  yz_conv | xy_pass  instead of
     // y | z_conv | y^-1 | x_pass.  Same spectrum positions and OTFs as the classic kernels.
     static bool two_pass_supported(Dims box);

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=0,
                     help="write only this many distinct input pairs and symlink the other time points to them (0 = all "
                          "distinct): lets a long batch (64 time points = 17 GB of stacks) fit a scratch disk")
+    ap.add_argument("--workers", default="",
+                    help="also run our main with this device list (argument 34, e.g. '0,0' = two worker threads sharing "
+                         "device 0; '0,1,2,3' on a multi-GPU node) and compare its stacks with the one-worker run")
     args = ap.parse_args()
 
     import torch
@@ -59,10 +62,10 @@ def main():
     del base_a, base_b
     torch.cuda.empty_cache()
 
-    def cli_args(out):
+    def cli_args(out, devices="0"):
         return [out + "/", w + "/SPIMA/", w + "/SPIMB/", "SPIMA_", "SPIMB_", "0", str(args.time_points - 1), "1", "0",
                 "1", "1", "1", "1", "1", "1", str(args.reg_mode), "0", "0", "none", "0.0001", "3000", "0", "0",
-                w + "/pa.tif", w + "/pb.tif", str(args.iters), "0", "0", "1", "0", "0", "16", "0", "0"]
+                w + "/pa.tif", w + "/pb.tif", str(args.iters), "0", "0", "1", "0", "0", "16", "0", devices]
 
     res = {}
     for name, exe in (("reference main, sequential I/O", os.path.join(ROOT, "oracle", "_ref", "cli", "spimFusionBatch")),
@@ -79,14 +82,29 @@ def main():
         if os.environ.get("MIL_BENCH_CLI_LOG"):  # per-phase seconds the tools print for every time point
             print(name, "\n".join(l for l in r.stdout.splitlines() if "ime cost" in l)[-1500:], file=sys.stderr)
         res[name] = {"seconds": round(dt, 3), "time_points_per_s": round(args.time_points / dt, 3)}
+    same_workers = None
+    if args.workers:
+        exe = os.path.join(ROOT, "microimagelib_amd", "bin", "spimFusionBatch")
+        out = w + "/out_workers"
+        t0 = time.perf_counter()
+        r = subprocess.run([exe] + cli_args(out, args.workers), capture_output=True, text=True, timeout=1800)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise SystemExit(r.stdout[-1500:] + r.stderr[-1500:])
+        res[f"our main, worker threads on devices {args.workers}"] = {"seconds": round(dt, 3),
+                                                                      "time_points_per_s": round(args.time_points / dt, 3)}
+        same_workers = all(open(f"{w}/out_workers/Decon/Decon_{t}.tif", "rb").read() == open(f"{w}/out_ours/Decon/Decon_{t}.tif", "rb").read()
+                           and open(f"{w}/out_workers/TMX/Matrix_{t}.tmx").read() == open(f"{w}/out_ours/TMX/Matrix_{t}.tmx").read()
+                           for t in range(args.time_points))
     same = None
-    if all(res.values()):
+    if all(v for k, v in res.items() if "worker" not in k):
         same = all(np.array_equal(api.readtifstack(f"{w}/out_ref/Decon/Decon_{t}.tif"),
                                   api.readtifstack(f"{w}/out_ours/Decon/Decon_{t}.tif")) for t in range(args.time_points))
     print(json.dumps({"workload": f"spimFusionBatch CLI, {args.time_points} time points 512x512x256, 16-bit TIFF in/out, "
                                   f"regMode {args.reg_mode}, {args.iters} RL iterations, process start to exit"
                                   + (f" ({args.distinct} distinct input pairs, the rest symlinked)" if args.distinct else ""),
-                      "results": res, "identical_decon_stacks": same}))
+                      "results": res, "identical_decon_stacks": same,
+                      "worker_threads_identical_to_one_worker": same_workers}))
     shutil.rmtree(w, ignore_errors=True)
 
 

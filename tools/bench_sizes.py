@@ -11,8 +11,8 @@ def gaussian_psf(shape, sig):
     g = [np.exp(-0.5 * ((np.arange(s) - s // 2) / sg) ** 2) for s, sg in zip(shape, sig)]
     return (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
 
-BOXES = [(64, 64, 64), (128, 128, 128), (128, 256, 256), (256, 256, 256), (256, 512, 512), (512, 512, 512),
-         (192, 192, 192), (256, 384, 384), (128, 320, 448), (256, 576, 640), (512, 1024, 1024)]
+BOXES = [(64, 64, 64), (128, 128, 128), (128, 256, 256), (256, 256, 256), (64, 512, 512), (128, 512, 512), (256, 512, 512),
+         (512, 512, 512), (192, 192, 192), (256, 384, 384), (128, 320, 448), (256, 576, 640), (512, 1024, 1024)]
 iters = 10
 rows = []
 for box in BOXES:
@@ -20,8 +20,20 @@ for box in BOXES:
     img = torch.rand(box, device="cuda", generator=g) * 1000 + 10
     psf = torch.from_numpy(gaussian_psf((31, 31, 31), (3.0, 1.5, 1.5))).cuda()
     res = {}
-    for name, backend in (("fused", 2), ("rocfft", 1)):
+    for name, backend in (("fused", 2), ("fused_classic", 2), ("rocfft", 1)):
+        # "fused" = the library's default for this box (two passes per convolution where csrc/fft2p.hip covers the box);
+        # "fused_classic" = the four-kernel sequence forced (MIL_FX_TWOPASS=0)
+        if name == "fused_classic":
+            os.environ["MIL_FX_TWOPASS"] = "0"
+        else:
+            os.environ.pop("MIL_FX_TWOPASS", None)
         eng = mdev.DeconEngine(box, backend=backend)
+        if name == "fused":
+            two_pass = eng.two_pass
+        if name == "fused_classic" and two_pass == 0:
+            eng.close()
+            res[name] = res["fused"]
+            continue
         otf, bp = eng.gen_otf(psf), eng.gen_otf(psf, flip=True)
         A = img.clone(); E = torch.empty_like(A)
         eng.init_single(A, E); eng.run_single(E, A, otf, bp, 2); eng.sync()
@@ -36,10 +48,12 @@ for box in BOXES:
     a, b = res["fused"][1], res["rocfft"][1]
     rel = float(((a - b).abs() / torch.clamp(b.abs(), min=float(b.abs().mean()))).max())
     vox = box[0] * box[1] * box[2]
-    rows.append({"box_zyx": box, "fused_it_s": round(res["fused"][0], 1), "rocfft_it_s": round(res["rocfft"][0], 1),
+    rows.append({"box_zyx": box, "two_pass": int(two_pass), "fused_it_s": round(res["fused"][0], 1),
+                 "fused_classic_it_s": round(res["fused_classic"][0], 1), "rocfft_it_s": round(res["rocfft"][0], 1),
                  "speedup": round(res["fused"][0] / res["rocfft"][0], 2),
                  "fused_GB_s_algorithmic": round(res["fused"][0] * (21 * 4 * vox) / 1e9, 0), "max_rel_diff": rel})
     print(rows[-1], flush=True)
+    os.environ.pop("MIL_FX_TWOPASS", None)
     del res, a, b, img
     torch.cuda.empty_cache()
 json.dump(rows, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "bench_sizes.json"), "w"), indent=1)
