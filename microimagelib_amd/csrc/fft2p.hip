@@ -13,11 +13,17 @@
 // twiddles and the OTF tiling are exactly those of the classic kernels (same in-place digit-reversed order), so both
 // paths share OTFs and can be mixed stage by stage (MIL_FX_TWOPASS, tests/test_gpu_fft.py).
 //
-// Boxes: 512 x 512 in x and y (the xy kernel holds the 64 rows y = n2 + 8m of one plane per thread and one column per
-// thread; it does not care about z), z = 256 (register yz kernel) or z = 128 / 64, where the yz tile (8 rows x 16 columns
-// x all z = 128 / 64 KB) FITS the LDS and yz_lds_kernel runs the same sequence with the classic LDS stage code.
+// Boxes (nx = 512 throughout: the xy kernel gives every spectrum column a thread).  Every column length of this library
+// starts its in-place transform with TWO radix-8 stages (fft_dev.h, pick_radix), so for any ny the "head" is 64 rows
+// y = n2 + T m (T = ny / 64) and the "tail" a transform of length T over T ADJACENT rows:
+//   xy_kernel<MODE, NY>      NY = 512, 256, 128 (T = 8, 4, 2): 64 rows of one plane per thread; does not care about z
+//   yz_conv_kernel           ny = 512, nz = 256: register tiles
+//   yz_lds_kernel<NY, NZ>    T x nz <= 1024: the tile of T rows x 16 columns x all z (<= 128 KB) FITS the LDS and the same
+//                            sequence runs on the classic LDS stage code
+// => 512 x {512, 256, 128} x {64, 128, 256} (x, y, z) and 512 x 128 x 512.
 #include "fftconv.h"
 
+#include <cstddef>
 #include <cstdlib>
 #include <vector>
 
@@ -28,7 +34,8 @@ namespace {
 
 #include "fft_dev.h"
 
-constexpr int kNY = 512, kNZ = 256, kNH = 256;  // x and y extents of every box of this path; kNZ: the register yz kernel's z
+constexpr int kNH = 256;              // nx = 512 in every box of this path
+constexpr int kNY = 512, kNZ = 256;  // the register yz kernel's y and z extents
 constexpr int kPitch = 272;                      // spectrum row pitch (ConvPlan: columns + 16)
 constexpr int kGroups = kNH / kW;                // 16-column groups per row
 
@@ -51,14 +58,26 @@ __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned vo
 // Twiddles of the in-register stages: their index is uniform over a wave, and from constant memory that is a scalar
 // load into SGPRs (through a kernel argument the compiler cannot prove the table read-only and fetches every twiddle
 // into a vector register: +40 registers, spills).  Filled by ConvPlan::init_two_pass on the current device.
-__constant__ float2 c_tw_y[kNY];
+// One table per y extent: engines of different boxes may live on the same device (host threads), and each writes only
+// its own table -- with the same values every time.
+struct TwYTables {
+    float2 w128[128], w256[256], w512[512];
+};
+__constant__ TwYTables c_tw_y;
 __constant__ float2 c_tw_z[kNZ];
+template <int NY>
+__device__ __forceinline__ const float2 *tw_y_const() {
+    static_assert(NY == 128 || NY == 256 || NY == 512, "two-pass path: y extent");
+    if constexpr (NY == 128) return c_tw_y.w128;
+    else if constexpr (NY == 256) return c_tw_y.w256;
+    else return c_tw_y.w512;
+}
 
 constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8;  // register yz kernel (nz = 256)
 constexpr long long kOtfBytes = (long long)kNH * kNY * kNZ * 8;
 
 // ---------------------------------------------------------------------------
-// partial y passes (classic column tiles): head = the stages of length > 8, tail = the stage of length 8
+// partial y passes (classic column tiles): head = the first two (radix-8) stages, tail = the sub-transforms of length T = N / 64
 // ---------------------------------------------------------------------------
 struct PartArgs {
     float2 *S;
@@ -70,6 +89,7 @@ struct PartArgs {
 
 template <int N, int NT, int PART>
 __global__ __launch_bounds__(NT) void col_part_kernel(PartArgs a) {
+    constexpr int T = N / 64;
     __shared__ float2 tile[N * kWP];
     __shared__ float2 tw[N];
     const int g = blockIdx.x % a.groups;
@@ -78,10 +98,10 @@ __global__ __launch_bounds__(NT) void col_part_kernel(PartArgs a) {
     for (int k = threadIdx.x; k < N; k += NT) tw[k] = a.tw[k];
     tile_load<N, NT>(tile, base, a.row_stride);
     lds_barrier();
-    if constexpr (PART == 0) fft_dif<N, N, -1, kW, NT, kWP, 8>(tile, tw);
-    else if constexpr (PART == 1) fft_dit<N, N, +1, kW, NT, 8>(tile, tw);
-    else if constexpr (PART == 2) fft_dif<N, 8, -1, kW, NT, kWP>(tile, tw);
-    else fft_dit<N, 8, +1, kW, NT>(tile, tw);
+    if constexpr (PART == 0) fft_dif<N, N, -1, kW, NT, kWP, T>(tile, tw);
+    else if constexpr (PART == 1) fft_dit<N, N, +1, kW, NT, T>(tile, tw);
+    else if constexpr (PART == 2) fft_dif<N, T, -1, kW, NT, kWP>(tile, tw);
+    else fft_dit<N, T, +1, kW, NT>(tile, tw);
     tile_store<N, NT>(tile, base, a.row_stride);
     if constexpr (PART == 2) {
         if (g == 0 && a.col0)
@@ -126,37 +146,40 @@ __device__ __forceinline__ float2 swap_pair(float2 a) {
 }
 
 // ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
-// One workgroup per pair of row blocks, 2 x 8 rows x NZ z of column 0 in LDS as tile[z][17].  `tw`: w_NZ^k, any address
+// One workgroup per pair of row blocks, 2 x T rows x NZ z of column 0 in LDS as tile[z][17].  `tw`: w_NZ^k, any address
 // space the 512 threads may index freely.
-template <int NZ>
+template <int NY, int NZ>
 __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *tile, const float2 *tw, int pair) {
+    constexpr int T = NY / 64, C = 2 * T;  // rows per block, columns of the tile in use
     const int tid = threadIdx.x;
     const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
-    for (int i = tid; i < NZ * 16; i += kYzThreads) {
-        const int c = i & 15, z = i >> 4;
-        tile[z * kWP + c] = a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch];
+    for (int i = tid; i < NZ * C; i += kYzThreads) {
+        const int c = i % C, z = i / C;
+        tile[z * kWP + c] = a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch];
     }
+    if (C < kW)  // the z stages below run over all 16 columns of the tile: keep the unused ones finite
+        for (int i = tid; i < NZ * (kW - C); i += kYzThreads) tile[(i / (kW - C)) * kWP + C + i % (kW - C)] = make_float2(0.f, 0.f);
     lds_barrier();
     for (int i = tid; i < NZ * 2; i += kYzThreads) {
-        float2 *p = tile + (i >> 1) * kWP + 8 * (i & 1);
-        float2 t[8];
+        float2 *p = tile + (i >> 1) * kWP + T * (i & 1);
+        float2 t[T];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = p[k];
-        dft8<-1>(t);
+        for (int k = 0; k < T; ++k) t[k] = p[k];
+        dft_small<T, -1>(t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = t[k];
+        for (int k = 0; k < T; ++k) p[k] = t[k];
     }
     lds_barrier();
     fft_dif<NZ, NZ, -1, kW, kYzThreads, kWP>(tile, tw);
-    constexpr int PER = (NZ * 16 + kYzThreads - 1) / kYzThreads;
+    constexpr int PER = (NZ * C + kYzThreads - 1) / kYzThreads;
     float2 r[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = i * kYzThreads + tid, c = e & 15, p = e >> 4;
-        if (e < NZ * 16) {
-            const int row = 8 * blk[c >> 3] + (c & 7);
+        const int e = i * kYzThreads + tid, c = e % C, p = e / C;
+        if (e < NZ * C) {
+            const int row = T * blk[c / T] + (c % T);
             const int prow = a.neg_y[row];
-            const int pc = ((prow >> 3) == blk[0] ? 0 : 8) + (prow & 7);
+            const int pc = ((prow / T) == blk[0] ? 0 : T) + (prow % T);
             const float2 gk = tile[p * kWP + c], gp = tile[a.neg_z[p] * kWP + pc];
             const float2 pv = a.otf[(((long long)row * kGroups) * NZ + p) * kW];
             const float2 qv = a.otf_q[(long long)row * NZ + p];
@@ -167,24 +190,24 @@ __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *til
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = i * kYzThreads + tid;
-        if (e < NZ * 16) tile[(e >> 4) * kWP + (e & 15)] = r[i];
+        if (e < NZ * C) tile[(e / C) * kWP + (e % C)] = r[i];
     }
     lds_barrier();
     fft_dit<NZ, NZ, +1, kW, kYzThreads>(tile, tw);
     for (int i = tid; i < NZ * 2; i += kYzThreads) {
-        float2 *p = tile + (i >> 1) * kWP + 8 * (i & 1);
-        float2 t[8];
+        float2 *p = tile + (i >> 1) * kWP + T * (i & 1);
+        float2 t[T];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = p[k];
-        dft8<+1>(t);
+        for (int k = 0; k < T; ++k) t[k] = p[k];
+        dft_small<T, +1>(t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = t[k];
+        for (int k = 0; k < T; ++k) p[k] = t[k];
     }
     lds_barrier();
-    const int ncol = (blk[0] == blk[1]) ? 8 : 16;
-    for (int i = tid; i < NZ * 16; i += kYzThreads) {
-        const int c = i & 15, z = i >> 4;
-        if (c < ncol) a.S[((long long)z * kNY + 8 * blk[c >> 3] + (c & 7)) * kPitch] = tile[z * kWP + c];
+    const int ncol = (blk[0] == blk[1]) ? T : C;
+    for (int i = tid; i < NZ * C; i += kYzThreads) {
+        const int c = i % C, z = i / C;
+        if (c < ncol) a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch] = tile[z * kWP + c];
     }
 }
 
@@ -371,74 +394,73 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
 #endif
         return;
     }
-    packed_column_block<kNZ>(a, lds, twz, (int)blockIdx.x);
+    packed_column_block<kNY, kNZ>(a, lds, twz, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
-// yz_conv for z <= 128: the 8 rows x 16 columns x NZ tile fits the LDS (NZ KB + padding), so the same sequence
-//   y stage(8) . z . OTF . z^-1 . y stage(8)^-1
-// runs on tile[z][8 rows x 16 columns] with the classic LDS stage code, 128 "columns" per z position.  One trip of the
+// yz_conv where the tile fits the LDS (T x NZ <= 1024, T = NY / 64 rows of the y tail): T rows x 16 columns x NZ z =
+// T * NZ / 8 KB + padding, so the same sequence
+//   y tail(T) . z . OTF . z^-1 . y tail(T)^-1
+// runs on tile[z][T rows x 16 columns] with the classic LDS stage code, T * 16 "columns" per z position.  One trip of the
 // spectrum through HBM (3 C'') where the classic kernels make three (y tail | z-conv | y tail^-1: 7 C'').
 // ---------------------------------------------------------------------------
-template <int NZ, int COLS>
+template <int NY, int NZ>
 __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
-    // COLS = 16: 128-byte row segments, tile = NZ KB; COLS = 8: 64-byte segments, half the tile -- two workgroups per CU
-    // at NZ = 128, whose load / transform / store phases then overlap
-    constexpr int W = 8 * COLS, WP = W + 1;  // row r, column c of the block sit at "column" r * COLS + c
-    constexpr int QR = COLS / 2;             // float4 pieces per row segment
+    constexpr int T = NY / 64;
+    static_assert(T * NZ <= 1024 && (T == 2 || T == 4 || T == 8), "yz_lds_kernel: tile does not fit the LDS");
+    constexpr int W = T * kW, WP = W + 1;  // row r, column c of the block sit at "column" r * 16 + c
+    constexpr int QR = kW / 2;             // float4 pieces per 128-byte row segment
     __shared__ float2 tile[NZ * WP > NZ * kWP ? NZ * WP : NZ * kWP];
     __shared__ float2 tw[NZ];
     const int tid = threadIdx.x;
     for (int k = tid; k < NZ; k += kYzThreads) tw[k] = tw_z[k];
     if ((int)blockIdx.x < a.pair_blocks) {
         lds_barrier();
-        packed_column_block<NZ>(a, tile, tw, (int)blockIdx.x);
+        packed_column_block<NY, NZ>(a, tile, tw, (int)blockIdx.x);
         return;
     }
-    constexpr int GROUPS = kNH / COLS;
     const int tile_id = blockIdx.x - a.pair_blocks;
-    const int g = tile_id % GROUPS, b = tile_id / GROUPS;
-    const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // the 16-column group of the OTF tiling, offset inside it
-    float2 *base = a.S + (long long)(8 * b) * kPitch + g * COLS;
-    constexpr long long zstride = (long long)kNY * kPitch;
-    // ---- load: NZ x 8 row segments
-    constexpr int TOTAL = NZ * 8 * QR;  // float4 pieces
+    const int g = tile_id % kGroups, b = tile_id / kGroups;
+    float2 *base = a.S + (long long)(T * b) * kPitch + g * kW;
+    constexpr long long zstride = (long long)NY * kPitch;
+    // ---- load: NZ x T row segments of 128 bytes
+    constexpr int TOTAL = NZ * T * QR;  // float4 pieces
 #pragma unroll 1
     for (int it0 = 0; it0 < TOTAL; it0 += kYzThreads * kBatch) {
         float4 v[kBatch];
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const int idx = it0 + j * kYzThreads + tid;
-            const int q = idx % QR, row = (idx / QR) & 7, z = idx / (8 * QR);
+            const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
             if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(base + z * zstride + (long long)row * kPitch + 2 * q);
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const int idx = it0 + j * kYzThreads + tid;
-            const int q = idx % QR, row = (idx / QR) & 7, z = idx / (8 * QR);
+            const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
             if (idx < TOTAL) {
-                float2 *p = tile + z * WP + row * COLS + 2 * q;
+                float2 *p = tile + z * WP + row * kW + 2 * q;
                 p[0] = make_float2(v[j].x, v[j].y);
                 p[1] = make_float2(v[j].z, v[j].w);
             }
         }
     }
     lds_barrier();
-    // ---- y stage of length 8 over the rows of every (z, column)
-    for (int i = tid; i < NZ * COLS; i += kYzThreads) {
-        float2 *p = tile + (i / COLS) * WP + (i % COLS);
-        float2 t[8];
+    // ---- y tail: the transform of length T over the rows of every (z, column)
+    for (int i = tid; i < NZ * kW; i += kYzThreads) {
+        float2 *p = tile + (i / kW) * WP + (i % kW);
+        float2 t[T];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = p[k * COLS];
-        dft8<-1>(t);
+        for (int k = 0; k < T; ++k) t[k] = p[k * kW];
+        dft_small<T, -1>(t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k * COLS] = t[k];
+        for (int k = 0; k < T; ++k) p[k * kW] = t[k];
     }
     lds_barrier();
     fft_dif<NZ, NZ, -1, W, kYzThreads, WP>(tile, tw);
-    // ---- OTF product: the classic tiling [row][16-column group][kz][16]
+    // ---- OTF product: the classic tiling [row][16-column group][kz][16]: one contiguous [NZ][16] block per row
     {
-        constexpr int PIECES = 8 * NZ * QR;  // float4 pieces
+        constexpr int PIECES = T * NZ * QR;  // float4 pieces
 #pragma unroll 1
         for (int it0 = 0; it0 < PIECES; it0 += kYzThreads * kBatch) {
             float4 v[kBatch];
@@ -447,14 +469,14 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
                 const int idx = it0 + j * kYzThreads + tid;
                 const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
                 if (idx < PIECES)
-                    v[j] = *reinterpret_cast<const float4 *>(a.otf + ((((long long)(8 * b + row) * kGroups + g16) * NZ + kz) * kW) + c16 + 2 * q);
+                    v[j] = *reinterpret_cast<const float4 *>(a.otf + ((((long long)(T * b + row) * kGroups + g) * NZ + kz) * kW) + 2 * q);
             }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 const int idx = it0 + j * kYzThreads + tid;
                 const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
                 if (idx < PIECES) {
-                    float2 *p = tile + kz * WP + row * COLS + 2 * q;
+                    float2 *p = tile + kz * WP + row * kW + 2 * q;
                     p[0] = c_mul(p[0], make_float2(v[j].x, v[j].y));
                     p[1] = c_mul(p[1], make_float2(v[j].z, v[j].w));
                 }
@@ -463,21 +485,21 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
     }
     lds_barrier();
     fft_dit<NZ, NZ, +1, W, kYzThreads>(tile, tw);
-    for (int i = tid; i < NZ * COLS; i += kYzThreads) {
-        float2 *p = tile + (i / COLS) * WP + (i % COLS);
-        float2 t[8];
+    for (int i = tid; i < NZ * kW; i += kYzThreads) {
+        float2 *p = tile + (i / kW) * WP + (i % kW);
+        float2 t[T];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = p[k * COLS];
-        dft8<+1>(t);
+        for (int k = 0; k < T; ++k) t[k] = p[k * kW];
+        dft_small<T, +1>(t);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k * COLS] = t[k];
+        for (int k = 0; k < T; ++k) p[k * kW] = t[k];
     }
     lds_barrier();
     // ---- store; the packed column (group 0, column 0) belongs to the pair blocks
 #pragma unroll 4
     for (int idx = tid; idx < TOTAL; idx += kYzThreads) {
-        const int q = idx % QR, row = (idx / QR) & 7, z = idx / (8 * QR);
-        const float2 *p = tile + z * WP + row * COLS + 2 * q;
+        const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
+        const float2 *p = tile + z * WP + row * kW + 2 * q;
         float2 *dst = base + z * zstride + (long long)row * kPitch + 2 * q;
         if (g == 0 && q == 0) dst[1] = p[1];
         else *reinterpret_cast<float4 *>(dst) = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
@@ -485,7 +507,7 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
 }
 
 // ---------------------------------------------------------------------------
-// xy pass: the 64 rows y = n2 + 8m of one z plane in registers (thread = column); y head^-1, then per 8 rows
+// xy pass: the 64 rows y = n2 + T m (T = NY / 64) of one z plane in registers (thread = column); y head^-1, then per 16 rows
 // x^-1 . op . x through LDS (the classic x kernel's tile), then y head
 // ---------------------------------------------------------------------------
 struct XyArgs {
@@ -499,8 +521,9 @@ struct XyArgs {
 };
 
 
-template <int MODE>
+template <int MODE, int NY>
 __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
+    constexpr int T = NY / 64;  // length of the y tail = distance between the rows of this workgroup
     constexpr int RB = 16, WP = RB + 1, NX = 2 * kNH;  // 16 rows per trip through LDS: tile[position][row]
     // position p of the half-length sequence, row r: tile[p * WP + (p >> 4) + r] -- the skew keeps the fold / split, which
     // step through the positions 16 at a time, from hammering two banks (54 % of the LDS cycles were conflicts without it)
@@ -508,8 +531,8 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     __shared__ float2 tw[kNH];       // w_NH^k = w_NX^(2k): the packed complex transform
     __shared__ float2 twx[kNH / 2];  // w_NX^k: Hermitian fold / split
     const int tid = threadIdx.x;
-    const int n2 = blockIdx.x & 7, z = blockIdx.x >> 3;
-    const float2 *twy = c_tw_y;
+    const int n2 = blockIdx.x % T, z = blockIdx.x / T;
+    const float2 *twy = tw_y_const<NY>();
     tw[tid] = a.tw_x[2 * tid];
     if (tid < kNH / 2) twx[tid] = a.tw_x[tid];
     // This thread's spectrum column is X[kc] (even columns) or X[NH - kc] (odd), kc = tid / 2; columns 0 / 1 are the packed
@@ -523,14 +546,14 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, a.spec_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, a.real_bytes);
     const unsigned voff = (unsigned)tid * 8u;
-    const unsigned soff0 = (unsigned)((z * kNY + n2) * kPitch) * 8u;  // + m * rstep
-    constexpr unsigned rstep = 8u * kPitch * 8u;
+    const unsigned soff0 = (unsigned)((z * NY + n2) * kPitch) * 8u;  // + m * rstep
+    constexpr unsigned rstep = (unsigned)T * kPitch * 8u;
     // middle stage: this thread owns butterfly i = tid & 15 (elements n = i + 16 j, real x = 2n, 2n + 1) of row tid >> 4 of
-    // the trip; tile row r is volume row y = n2 + 8 r + 128 grp
+    // the trip; tile row r is volume row y = n2 + T r + 16 T grp
     const int bi = tid & 15, br = tid >> 4;
-    const unsigned rvoff = (unsigned)(br * 8 * NX + 2 * bi) * 4u;
-    const unsigned rsoff0 = (unsigned)((z * kNY + n2) * NX) * 4u;  // + grp * 128 rows, + 32 j floats
-    constexpr unsigned rgrp = 128u * NX * 4u, rj = 32u * 4u;
+    const unsigned rvoff = (unsigned)(br * T * NX + 2 * bi) * 4u;
+    const unsigned rsoff0 = (unsigned)((z * NY + n2) * NX) * 4u;  // + grp * 16 T rows, + 32 j floats
+    constexpr unsigned rgrp = 16u * T * NX * 4u, rj = 32u * 4u;
     float2 v[64];
     float2 pre[16];  // the trip's slice of M / E (element j of the butterfly), requested one trip ahead
     MIL_STAMP(0);
@@ -538,7 +561,8 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * rstep);
 #pragma unroll
     for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff0 + q * rj);
-    // ---- y inverse head: DIT stages L = 64 (over j2, m = j2 + 8 j1) and L = 512 (over j1)
+    // ---- y inverse head: DIT stages L = NY / 8 (over j2, m = j2 + 8 j1; element i = n2 of its sub-transform) and L = NY
+    // (over j1; element i = n2 + T j2)
 #pragma unroll
     for (int j1 = 0; j1 < 8; ++j1) {
         float2 t[8];
@@ -556,7 +580,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twy[(n2 + 8 * j2) * k]);
+        for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twy[(n2 + T * j2) * k]);
         dft8<+1>(t);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
@@ -656,7 +680,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
     }
     MIL_STAMP(3);
     if constexpr (MODE == kXUpdateLast) return;
-    // ---- y forward head: DIF stages L = 512 (over j1) and L = 64 (over j2)
+    // ---- y forward head: DIF stages L = NY (over j1) and L = NY / 8 (over j2)
 #pragma unroll
     for (int j2 = 0; j2 < 8; ++j2) {
         float2 t[8];
@@ -664,7 +688,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
         for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
         dft8<-1>(t);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twy[(n2 + 8 * j2) * k]);
+        for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twy[(n2 + T * j2) * k]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
     }
@@ -696,29 +720,35 @@ unsigned long long *g_stamps = nullptr;  // set through mil_fx_set_stamps (timin
 }  // namespace
 
 bool ConvPlan::two_pass_supported(Dims b) {
-    return b.nx == 2 * kNH && b.ny == kNY && (b.nz == kNZ || b.nz == 128 || b.nz == 64);
+    if (b.nx != 2 * kNH) return false;
+    if (b.ny != 512 && b.ny != 256 && b.ny != 128) return false;
+    const long long t = b.ny / 64;
+    if (b.ny == kNY && b.nz == kNZ) return true;                              // register yz kernel
+    return (b.nz == 64 || b.nz == 128 || b.nz == 256 || b.nz == 512) && t * b.nz <= 1024;  // LDS-resident yz kernel
 }
 
 void ConvPlan::init_two_pass() {
     if (!two_pass_supported(box_) || pitch_ != kPitch) return;
-    // pairs of 8-row blocks holding ky and -ky
-    std::vector<unsigned short> fy((size_t)kNY), pos((size_t)kNY), pairs;
-    digit_reversal_freq(kNY, fy.data());
-    for (int q = 0; q < kNY; ++q) pos[fy[(size_t)q]] = (unsigned short)q;
-    for (int b = 0; b < kNY / 8; ++b) {
-        const int nb = pos[(size_t)((kNY - fy[(size_t)(8 * b)]) % kNY)] / 8;
-        for (int j = 0; j < 8; ++j)
-            if (pos[(size_t)((kNY - fy[(size_t)(8 * b + j)]) % kNY)] / 8 != nb) throw Error(-1, "two-pass plan: row blocks do not pair up");
+    const int ny = (int)box_.ny, T = ny / 64;
+    // pairs of T-row blocks holding ky and -ky
+    std::vector<unsigned short> fy((size_t)ny), pos((size_t)ny), pairs;
+    digit_reversal_freq(ny, fy.data());
+    for (int q = 0; q < ny; ++q) pos[fy[(size_t)q]] = (unsigned short)q;
+    for (int b = 0; b < ny / T; ++b) {
+        const int nb = pos[(size_t)((ny - fy[(size_t)(T * b)]) % ny)] / T;
+        for (int j = 0; j < T; ++j)
+            if (pos[(size_t)((ny - fy[(size_t)(T * b + j)]) % ny)] / T != nb) return;  // blocks do not pair up: classic path
         if (nb >= b) {
             pairs.push_back((unsigned short)b);
             pairs.push_back((unsigned short)nb);
         }
     }
     {
-        std::vector<float2> ty((size_t)kNY);
+        std::vector<float2> ty((size_t)ny);
         MIL_HIP(hipMemcpy(ty.data(), tw_y_.get(), ty.size() * sizeof(float2), hipMemcpyDeviceToHost));
-        MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_y), ty.data(), ty.size() * sizeof(float2)));
-        if (box_.nz == kNZ) {  // the register yz kernel reads its z twiddles from constant memory
+        const size_t off = ny == 128 ? offsetof(TwYTables, w128) : ny == 256 ? offsetof(TwYTables, w256) : offsetof(TwYTables, w512);
+        MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_y), ty.data(), ty.size() * sizeof(float2), off));
+        if (ny == kNY && box_.nz == kNZ) {  // the register yz kernel reads its z twiddles from constant memory
             std::vector<float2> tz((size_t)kNZ);
             MIL_HIP(hipMemcpy(tz.data(), tw_z_.get(), tz.size() * sizeof(float2), hipMemcpyDeviceToHost));
             MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_z), tz.data(), tz.size() * sizeof(float2)));
@@ -732,17 +762,22 @@ void ConvPlan::init_two_pass() {
 
 void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
+    if (part < 0 || part > 3) throw Error(-1, "y_part: unknown part");
     PartArgs a;
     a.S = S; a.tw = tw_y_.get(); a.col0 = (part == 2) ? col0_.get() : nullptr;
     a.row_stride = pitch_; a.outer_stride = (long long)box_.ny * pitch_; a.groups = xs_ / kW;
-    const dim3 grid((unsigned)(a.groups * box_.nz)), block(512);
-    switch (part) {
-        case 0: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 0>), grid, block, 0, s, a); break;
-        case 1: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 1>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 2>), grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((col_part_kernel<kNY, 512, 3>), grid, block, 0, s, a); break;
-        default: throw Error(-1, "y_part: unknown part");
+    const dim3 grid((unsigned)(a.groups * box_.nz));
+#define MIL_PART(N, NT)                                                                                        \
+    switch (part) {                                                                                            \
+        case 0: hipLaunchKernelGGL((col_part_kernel<N, NT, 0>), grid, dim3(NT), 0, s, a); break;               \
+        case 1: hipLaunchKernelGGL((col_part_kernel<N, NT, 1>), grid, dim3(NT), 0, s, a); break;               \
+        case 2: hipLaunchKernelGGL((col_part_kernel<N, NT, 2>), grid, dim3(NT), 0, s, a); break;               \
+        default: hipLaunchKernelGGL((col_part_kernel<N, NT, 3>), grid, dim3(NT), 0, s, a); break;              \
     }
+    if (box_.ny == 512) { MIL_PART(512, 512) }
+    else if (box_.ny == 256) { MIL_PART(256, 256) }
+    else { MIL_PART(128, 256) }
+#undef MIL_PART
     MIL_HIP(hipGetLastError());
 }
 
@@ -753,30 +788,48 @@ void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     a.neg_y = neg_y_.get(); a.neg_z = neg_z_.get(); a.pairs = pairs_.get();
     a.pair_blocks = n_pairs_;
     a.stamps = g_stamps;
-    const dim3 grid((unsigned)((kNY / 8) * kGroups + n_pairs_));
-    // (8-column tiles -- 64-byte segments, two workgroups per CU at nz = 128 -- measured: 2 200 against 2 170 it/s, within
-    // noise, profiles/r03/bench_box_nz128.txt; the 16-column form stays)
-    if (box_.nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel, grid, dim3(kYzThreads), 0, s, a);
-    else if (box_.nz == 128) hipLaunchKernelGGL((yz_lds_kernel<128, 16>), grid, dim3(kYzThreads), 0, s, a, (const float2 *)tw_z_.get());
-    else hipLaunchKernelGGL((yz_lds_kernel<64, 16>), grid, dim3(kYzThreads), 0, s, a, (const float2 *)tw_z_.get());
+    const dim3 grid((unsigned)(64 * kGroups + n_pairs_)), block(kYzThreads);  // 64 blocks of T rows, whatever ny is
+    const float2 *twz = tw_z_.get();
+    const int ny = (int)box_.ny, nz = (int)box_.nz;
+    // (8-column tiles -- 64-byte segments, two workgroups per CU at 512 x 512 x 128 -- measured: 2 200 against 2 170 it/s,
+    // within noise, profiles/r03/bench_box_nz128.txt; the 16-column form stays)
+#define MIL_YZ(NY, NZ) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ>), grid, block, 0, s, a, twz)
+    if (ny == kNY && nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel, grid, block, 0, s, a);
+    else if (ny == 512 && nz == 128) MIL_YZ(512, 128);
+    else if (ny == 512 && nz == 64) MIL_YZ(512, 64);
+    else if (ny == 256 && nz == 256) MIL_YZ(256, 256);
+    else if (ny == 256 && nz == 128) MIL_YZ(256, 128);
+    else if (ny == 256 && nz == 64) MIL_YZ(256, 64);
+    else if (ny == 128 && nz == 512) MIL_YZ(128, 512);
+    else if (ny == 128 && nz == 256) MIL_YZ(128, 256);
+    else if (ny == 128 && nz == 128) MIL_YZ(128, 128);
+    else if (ny == 128 && nz == 64) MIL_YZ(128, 64);
+    else throw Error(-1, "yz_conv: box outside the two-pass path");
+#undef MIL_YZ
     MIL_HIP(hipGetLastError());
 }
 
 void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float eps, hipStream_t s) const {
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
     if (!S || (mode == kXRatio ? !M : !E)) throw Error(-1, "xy_pass: missing operand");
+    if (mode != kXRatio && mode != kXUpdate && mode != kXUpdateLast) throw Error(-1, "xy_pass: mode must be ratio / update");
     XyArgs a;
     a.S = S; a.E = E; a.M = M; a.tw_x = tw_x_.get(); a.eps = eps;
-    a.spec_bytes = (long long)kPitch * kNY * box_.nz * 8;
-    a.real_bytes = 2LL * kNH * kNY * box_.nz * 4;
+    a.spec_bytes = (long long)kPitch * box_.ny * box_.nz * 8;
+    a.real_bytes = 2LL * kNH * box_.ny * box_.nz * 4;
     a.stamps = (g_stamps && mode == kXRatio) ? g_stamps + 2048 * 16 : nullptr;
-    const dim3 grid((unsigned)(box_.nz * 8)), block(kNT);
-    switch (mode) {
-        case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio>), grid, block, 0, s, a); break;
-        case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate>), grid, block, 0, s, a); break;
-        case kXUpdateLast: hipLaunchKernelGGL((xy_kernel<kXUpdateLast>), grid, block, 0, s, a); break;
-        default: throw Error(-1, "xy_pass: mode must be ratio / update");
+    const int T = (int)box_.ny / 64;
+    const dim3 grid((unsigned)(box_.nz * T)), block(kNT);
+#define MIL_XY(NY)                                                                                           \
+    switch (mode) {                                                                                          \
+        case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio, NY>), grid, block, 0, s, a); break;             \
+        case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate, NY>), grid, block, 0, s, a); break;           \
+        default: hipLaunchKernelGGL((xy_kernel<kXUpdateLast, NY>), grid, block, 0, s, a); break;             \
     }
+    if (box_.ny == 512) { MIL_XY(512) }
+    else if (box_.ny == 256) { MIL_XY(256) }
+    else { MIL_XY(128) }
+#undef MIL_XY
     MIL_HIP(hipGetLastError());
 }
 
