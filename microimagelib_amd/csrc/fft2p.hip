@@ -13,18 +13,21 @@
 // twiddles and the OTF tiling are exactly those of the classic kernels (same in-place digit-reversed order), so both
 // paths share OTFs and can be mixed stage by stage (MIL_FX_TWOPASS, tests/test_gpu_fft.py).
 //
-// Boxes (nx = 512 throughout: the xy kernel gives every spectrum column a thread).  Every column length of this library
+// Boxes.  nx = 256, 512, 1024 (NH = nx / 2 = 128, 256, 512 spectrum columns: the xy kernel gives every column a thread
+// and runs its x transform as NH = 16 x M: an LDS stage of length M = NH / 16 and a radix-16 stage in registers, fused with
+// the real-space operation).  Every column length of this library
 // starts its in-place transform with TWO radix-8 stages (fft_dev.h, pick_radix), so for any ny the "head" is 64 rows
 // y = n2 + T m (T = ny / 64) and the "tail" a transform of length T over T ADJACENT rows:
 //   xy_kernel<MODE, NY>      NY = 512, 256, 128 (T = 8, 4, 2): 64 rows of one plane per thread; does not care about z
 //   yz_conv_kernel           ny = 512, nz = 256: register tiles
 //   yz_lds_kernel<NY, NZ>    T x nz <= 1024: the tile of T rows x 16 columns x all z (<= 128 KB) FITS the LDS and the same
 //                            sequence runs on the classic LDS stage code
-// => 512 x {512, 256, 128} x {64, 128, 256} (x, y, z) and 512 x 128 x 512.
+// => {256, 512, 1024} x {512, 256, 128} x {64, 128, 256} (x, y, z) and ... x 128 x 512: 30 boxes.
 #include "fftconv.h"
 
 #include <cstddef>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace mil {
@@ -34,10 +37,14 @@ namespace {
 
 #include "fft_dev.h"
 
-constexpr int kNH = 256;              // nx = 512 in every box of this path
 constexpr int kNY = 512, kNZ = 256;  // the register yz kernel's y and z extents
-constexpr int kPitch = 272;                      // spectrum row pitch (ConvPlan: columns + 16)
-constexpr int kGroups = kNH / kW;                // 16-column groups per row
+// NH = nx / 2 spectrum columns (template parameter of every kernel): row pitch NH + 16 (ConvPlan: columns + 16), NH / 16
+// 16-column groups per row
+template <int NH>
+struct Geo {
+    static_assert(NH == 128 || NH == 256 || NH == 512, "two-pass path: nx must be 256, 512 or 1024");
+    static constexpr int pitch = NH + kW, groups = NH / kW;
+};
 
 // Buffer addressing: one 32-bit lane offset + a scalar offset per access, so that the 64 accesses of a register tile
 // share ONE address register instead of 64 pointer pairs.
@@ -73,8 +80,6 @@ __device__ __forceinline__ const float2 *tw_y_const() {
     else return c_tw_y.w512;
 }
 
-constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8;  // register yz kernel (nz = 256)
-constexpr long long kOtfBytes = (long long)kNH * kNY * kNZ * 8;
 
 // ---------------------------------------------------------------------------
 // partial y passes (classic column tiles): head = the first two (radix-8) stages, tail = the sub-transforms of length T = N / 64
@@ -148,9 +153,10 @@ __device__ __forceinline__ float2 swap_pair(float2 a) {
 // ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
 // One workgroup per pair of row blocks, 2 x T rows x NZ z of column 0 in LDS as tile[z][17].  `tw`: w_NZ^k, any address
 // space the 512 threads may index freely.
-template <int NY, int NZ>
+template <int NY, int NZ, int NH>
 __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *tile, const float2 *tw, int pair) {
     constexpr int T = NY / 64, C = 2 * T;  // rows per block, columns of the tile in use
+    constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
     const int tid = threadIdx.x;
     const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
     for (int i = tid; i < NZ * C; i += kYzThreads) {
@@ -211,7 +217,10 @@ __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *til
     }
 }
 
+template <int NH>
 __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
+    constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
+    constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8, kOtfBytes = (long long)NH * kNY * kNZ * 8;
     // exchange buffer of one quarter (66 KB) + parking space (92 KB): registers are the scarce resource of this kernel,
     // every spilled one is HBM traffic
     __shared__ float2 lds[kQuarter * kXchg + kPark * kYzThreads];
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
 #endif
         return;
     }
-    packed_column_block<kNY, kNZ>(a, lds, twz, (int)blockIdx.x);
+    packed_column_block<kNY, kNZ, NH>(a, lds, twz, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -404,9 +413,10 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
 // runs on tile[z][T rows x 16 columns] with the classic LDS stage code, T * 16 "columns" per z position.  One trip of the
 // spectrum through HBM (3 C'') where the classic kernels make three (y tail | z-conv | y tail^-1: 7 C'').
 // ---------------------------------------------------------------------------
-template <int NY, int NZ>
+template <int NY, int NZ, int NH>
 __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
     constexpr int T = NY / 64;
+    constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
     static_assert(T * NZ <= 1024 && (T == 2 || T == 4 || T == 8), "yz_lds_kernel: tile does not fit the LDS");
     constexpr int W = T * kW, WP = W + 1;  // row r, column c of the block sit at "column" r * 16 + c
     constexpr int QR = kW / 2;             // float4 pieces per 128-byte row segment
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
     for (int k = tid; k < NZ; k += kYzThreads) tw[k] = tw_z[k];
     if ((int)blockIdx.x < a.pair_blocks) {
         lds_barrier();
-        packed_column_block<NY, NZ>(a, tile, tw, (int)blockIdx.x);
+        packed_column_block<NY, NZ, NH>(a, tile, tw, (int)blockIdx.x);
         return;
     }
     const int tile_id = blockIdx.x - a.pair_blocks;
@@ -521,39 +531,67 @@ struct XyArgs {
 };
 
 
-template <int MODE, int NY>
-__global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
+// The x transform of length NH runs as NH = 16 x M: element k = a + 16 b (a < 16, b < M) of the half-length sequence sits at
+// position a * M + pos_M(b), where pos_M is the in-place order of the length-M sub-transforms (one radix-8 / radix-16 LDS
+// stage for M = 8 / 16: the identity; radix 8 then radix 4 for M = 32: 4 (b % 8) + b / 8).
+template <int M>
+__device__ __forceinline__ int xy_pos_m(int b) {
+    return M == 32 ? 4 * (b & 7) + (b >> 3) : b;
+}
+
+// the LDS stage(s) of length M = NH / 16 of the x transform, on the skewed 16-row tile
+template <int NH, bool DIT, int SIGN>
+__device__ __forceinline__ void xy_stage_m(float2 *tile, const float2 *tw) {
+    constexpr int M = NH / 16, RB = 16;
+    if constexpr (M == 32) {  // radix 8 . radix 4 (the schedule of fft_dif / fft_dit for length 32)
+        if constexpr (DIT) {
+            fft_stage<NH, 4, 4, true, SIGN, RB, NH, RB + 1, M>(tile, tw);
+            lds_barrier();
+            fft_stage<NH, 8, 32, true, SIGN, RB, NH, RB + 1, M>(tile, tw);
+        } else {
+            fft_stage<NH, 8, 32, false, SIGN, RB, NH, RB + 1, M>(tile, tw);
+            lds_barrier();
+            fft_stage<NH, 4, 4, false, SIGN, RB, NH, RB + 1, M>(tile, tw);
+        }
+    } else {
+        fft_stage<NH, M, M, DIT, SIGN, RB, NH, RB + 1, M>(tile, tw);
+    }
+}
+
+template <int MODE, int NY, int NH>
+__global__ __launch_bounds__(NH, 2) void xy_kernel(XyArgs a) {
     constexpr int T = NY / 64;  // length of the y tail = distance between the rows of this workgroup
-    constexpr int RB = 16, WP = RB + 1, NX = 2 * kNH;  // 16 rows per trip through LDS: tile[position][row]
-    // position p of the half-length sequence, row r: tile[p * WP + (p >> 4) + r] -- the skew keeps the fold / split, which
-    // step through the positions 16 at a time, from hammering two banks (54 % of the LDS cycles were conflicts without it)
-    __shared__ float2 tile[kNH * WP + 16];
-    __shared__ float2 tw[kNH];       // w_NH^k = w_NX^(2k): the packed complex transform
-    __shared__ float2 twx[kNH / 2];  // w_NX^k: Hermitian fold / split
+    constexpr int M = NH / 16;  // length of the LDS stage of the x transform
+    constexpr int kPitch = Geo<NH>::pitch;
+    constexpr int RB = 16, WP = RB + 1, NX = 2 * NH;  // 16 rows per trip through LDS: tile[position][row]
+    // position p of the half-length sequence, row r: tile[p * WP + p / M + r] -- the skew keeps the fold / split, which
+    // step through the positions M at a time, from hammering two banks (54 % of the LDS cycles were conflicts without it)
+    __shared__ float2 tile[NH * WP + 16];
+    __shared__ float2 tw[NH];       // w_NH^k = w_NX^(2k): the packed complex transform
+    __shared__ float2 twx[NH / 2];  // w_NX^k: Hermitian fold / split
     const int tid = threadIdx.x;
     const int n2 = blockIdx.x % T, z = blockIdx.x / T;
     const float2 *twy = tw_y_const<NY>();
     tw[tid] = a.tw_x[2 * tid];
-    if (tid < kNH / 2) twx[tid] = a.tw_x[tid];
+    if (tid < NH / 2) twx[tid] = a.tw_x[tid];
     // This thread's spectrum column is X[kc] (even columns) or X[NH - kc] (odd), kc = tid / 2; columns 0 / 1 are the packed
     // (X[0], X[NH]) and X[NH/2].  The element of the half-length sequence it folds to / splits from sits at position pz.
     const int kc = tid >> 1;
     const bool odd = tid & 1;
-    // (the x transform of this kernel is 16 x 16: element k = a + 16 b of the half-length sequence sits at position 16 a + b)
-    const int ez = tid == 1 ? kNH / 2 : (odd ? kNH - kc : kc);
-    const int pz = 16 * (ez & 15) + (ez >> 4);
-    const int pzs = pz * WP + (pz >> 4);  // its place in the skewed tile
+    const int ez = tid == 1 ? NH / 2 : (odd ? NH - kc : kc);
+    const int pz = M * (ez & 15) + xy_pos_m<M>(ez >> 4);
+    const int pzs = pz * WP + pz / M;  // its place in the skewed tile
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, a.spec_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, a.real_bytes);
     const unsigned voff = (unsigned)tid * 8u;
     const unsigned soff0 = (unsigned)((z * NY + n2) * kPitch) * 8u;  // + m * rstep
     constexpr unsigned rstep = (unsigned)T * kPitch * 8u;
-    // middle stage: this thread owns butterfly i = tid & 15 (elements n = i + 16 j, real x = 2n, 2n + 1) of row tid >> 4 of
-    // the trip; tile row r is volume row y = n2 + T r + 16 T grp
-    const int bi = tid & 15, br = tid >> 4;
+    // middle stage: this thread owns butterfly i = tid % M (elements n = i + M j, j < 16; real x = 2n, 2n + 1) of row
+    // tid / M of the trip; tile row r is volume row y = n2 + T r + 16 T grp
+    const int bi = tid % M, br = tid / M;
     const unsigned rvoff = (unsigned)(br * T * NX + 2 * bi) * 4u;
-    const unsigned rsoff0 = (unsigned)((z * NY + n2) * NX) * 4u;  // + grp * 16 T rows, + 32 j floats
-    constexpr unsigned rgrp = 16u * T * NX * 4u, rj = 32u * 4u;
+    const unsigned rsoff0 = (unsigned)((z * NY + n2) * NX) * 4u;  // + grp * 16 T rows, + 2 M j floats
+    constexpr unsigned rgrp = 16u * T * NX * 4u, rj = 2u * M * 4u;
     float2 v[64];
     float2 pre[16];  // the trip's slice of M / E (element j of the butterfly), requested one trip ahead
     MIL_STAMP(0);
@@ -612,7 +650,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
         if (grp == 0) MIL_STAMP(8);
         lds_barrier();
         if (grp == 0) MIL_STAMP(9);
-        fft_stage<kNH, 16, 16, true, +1, RB, kNT, RB + 1, true>(tile, tw);  // DIT stage L = 16; the other one (L = 256) is fused below
+        xy_stage_m<NH, true, +1>(tile, tw);  // DIT stage(s) of length M; the radix-16 stage of length NH is fused below
         lds_barrier();
         if (grp == 0) MIL_STAMP(10);
         // ---- last inverse stage, real-space operation, first forward stage on the butterfly's 16 elements
@@ -620,7 +658,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
             float2 *p = tile + bi * WP + br;
             float2 t[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) t[j] = p[j * (16 * WP + 1)];
+            for (int j = 0; j < 16; ++j) t[j] = p[j * (M * WP + 1)];
 #pragma unroll
             for (int k = 1; k < 16; ++k) t[k] = tw_mul<+1>(t[k], tw[bi * k]);
             dft16<+1>(t);
@@ -642,7 +680,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
 #pragma unroll
                 for (int k = 1; k < 16; ++k) t[k] = tw_mul<-1>(t[k], tw[bi * k]);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) p[j * (16 * WP + 1)] = t[j];
+                for (int j = 0; j < 16; ++j) p[j * (M * WP + 1)] = t[j];
             }
         }
         if (grp + 1 < 64 / RB) {  // next trip's M / E: in flight during the forward stages and the next fold
@@ -657,7 +695,7 @@ __global__ __launch_bounds__(kNT, 2) void xy_kernel(XyArgs a) {
             continue;
         }
         lds_barrier();
-        fft_stage<kNH, 16, 16, false, -1, RB, kNT, RB + 1, true>(tile, tw);  // DIF stage L = 16
+        xy_stage_m<NH, false, -1>(tile, tw);  // DIF stage(s) of length M
         lds_barrier();
         if (grp == 0) MIL_STAMP(12);
         // Hermitian split back into this thread's column: each lane picks up its element Z[k] / Z[NH-k], the pair swaps.
@@ -720,7 +758,7 @@ unsigned long long *g_stamps = nullptr;  // set through mil_fx_set_stamps (timin
 }  // namespace
 
 bool ConvPlan::two_pass_supported(Dims b) {
-    if (b.nx != 2 * kNH) return false;
+    if (b.nx != 256 && b.nx != 512 && b.nx != 1024) return false;
     if (b.ny != 512 && b.ny != 256 && b.ny != 128) return false;
     const long long t = b.ny / 64;
     if (b.ny == kNY && b.nz == kNZ) return true;                              // register yz kernel
@@ -728,7 +766,7 @@ bool ConvPlan::two_pass_supported(Dims b) {
 }
 
 void ConvPlan::init_two_pass() {
-    if (!two_pass_supported(box_) || pitch_ != kPitch) return;
+    if (!two_pass_supported(box_) || pitch_ != (int)box_.nx / 2 + kW || xs_ != (int)box_.nx / 2) return;
     const int ny = (int)box_.ny, T = ny / 64;
     // pairs of T-row blocks holding ky and -ky
     std::vector<unsigned short> fy((size_t)ny), pos((size_t)ny), pairs;
@@ -760,6 +798,17 @@ void ConvPlan::init_two_pass() {
     two_pass_ = true;
 }
 
+namespace {
+// run f(std::integral_constant<int, NH>) for the plan's NH
+template <class F>
+void with_nh(long long nx, F &&f) {
+    if (nx == 256) f(std::integral_constant<int, 128>{});
+    else if (nx == 512) f(std::integral_constant<int, 256>{});
+    else if (nx == 1024) f(std::integral_constant<int, 512>{});
+    else throw Error(-1, "two-pass path: nx must be 256, 512 or 1024");
+}
+}  // namespace
+
 void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
     if (part < 0 || part > 3) throw Error(-1, "y_part: unknown part");
@@ -788,24 +837,27 @@ void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     a.neg_y = neg_y_.get(); a.neg_z = neg_z_.get(); a.pairs = pairs_.get();
     a.pair_blocks = n_pairs_;
     a.stamps = g_stamps;
-    const dim3 grid((unsigned)(64 * kGroups + n_pairs_)), block(kYzThreads);  // 64 blocks of T rows, whatever ny is
+    const dim3 grid((unsigned)(64 * (xs_ / kW) + n_pairs_)), block(kYzThreads);  // 64 blocks of T rows, whatever ny is
     const float2 *twz = tw_z_.get();
     const int ny = (int)box_.ny, nz = (int)box_.nz;
     // (8-column tiles -- 64-byte segments, two workgroups per CU at 512 x 512 x 128 -- measured: 2 200 against 2 170 it/s,
     // within noise, profiles/r03/bench_box_nz128.txt; the 16-column form stays)
-#define MIL_YZ(NY, NZ) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ>), grid, block, 0, s, a, twz)
-    if (ny == kNY && nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel, grid, block, 0, s, a);
-    else if (ny == 512 && nz == 128) MIL_YZ(512, 128);
-    else if (ny == 512 && nz == 64) MIL_YZ(512, 64);
-    else if (ny == 256 && nz == 256) MIL_YZ(256, 256);
-    else if (ny == 256 && nz == 128) MIL_YZ(256, 128);
-    else if (ny == 256 && nz == 64) MIL_YZ(256, 64);
-    else if (ny == 128 && nz == 512) MIL_YZ(128, 512);
-    else if (ny == 128 && nz == 256) MIL_YZ(128, 256);
-    else if (ny == 128 && nz == 128) MIL_YZ(128, 128);
-    else if (ny == 128 && nz == 64) MIL_YZ(128, 64);
-    else throw Error(-1, "yz_conv: box outside the two-pass path");
+    with_nh(box_.nx, [&](auto nh_tag) {
+        constexpr int NH = decltype(nh_tag)::value;
+#define MIL_YZ(NY, NZ) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ, NH>), grid, block, 0, s, a, twz)
+        if (ny == kNY && nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel<NH>, grid, block, 0, s, a);
+        else if (ny == 512 && nz == 128) MIL_YZ(512, 128);
+        else if (ny == 512 && nz == 64) MIL_YZ(512, 64);
+        else if (ny == 256 && nz == 256) MIL_YZ(256, 256);
+        else if (ny == 256 && nz == 128) MIL_YZ(256, 128);
+        else if (ny == 256 && nz == 64) MIL_YZ(256, 64);
+        else if (ny == 128 && nz == 512) MIL_YZ(128, 512);
+        else if (ny == 128 && nz == 256) MIL_YZ(128, 256);
+        else if (ny == 128 && nz == 128) MIL_YZ(128, 128);
+        else if (ny == 128 && nz == 64) MIL_YZ(128, 64);
+        else throw Error(-1, "yz_conv: box outside the two-pass path");
 #undef MIL_YZ
+    });
     MIL_HIP(hipGetLastError());
 }
 
@@ -815,21 +867,25 @@ void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float ep
     if (mode != kXRatio && mode != kXUpdate && mode != kXUpdateLast) throw Error(-1, "xy_pass: mode must be ratio / update");
     XyArgs a;
     a.S = S; a.E = E; a.M = M; a.tw_x = tw_x_.get(); a.eps = eps;
-    a.spec_bytes = (long long)kPitch * box_.ny * box_.nz * 8;
-    a.real_bytes = 2LL * kNH * box_.ny * box_.nz * 4;
+    a.spec_bytes = (long long)pitch_ * box_.ny * box_.nz * 8;
+    a.real_bytes = (long long)box_.nx * box_.ny * box_.nz * 4;
     a.stamps = (g_stamps && mode == kXRatio) ? g_stamps + 2048 * 16 : nullptr;
     const int T = (int)box_.ny / 64;
-    const dim3 grid((unsigned)(box_.nz * T)), block(kNT);
-#define MIL_XY(NY)                                                                                           \
-    switch (mode) {                                                                                          \
-        case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio, NY>), grid, block, 0, s, a); break;             \
-        case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate, NY>), grid, block, 0, s, a); break;           \
-        default: hipLaunchKernelGGL((xy_kernel<kXUpdateLast, NY>), grid, block, 0, s, a); break;             \
+    const dim3 grid((unsigned)(box_.nz * T));
+    with_nh(box_.nx, [&](auto nh_tag) {
+        constexpr int NH = decltype(nh_tag)::value;
+        const dim3 block(NH);
+#define MIL_XY(NY)                                                                                               \
+    switch (mode) {                                                                                              \
+        case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio, NY, NH>), grid, block, 0, s, a); break;             \
+        case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate, NY, NH>), grid, block, 0, s, a); break;           \
+        default: hipLaunchKernelGGL((xy_kernel<kXUpdateLast, NY, NH>), grid, block, 0, s, a); break;             \
     }
-    if (box_.ny == 512) { MIL_XY(512) }
-    else if (box_.ny == 256) { MIL_XY(256) }
-    else { MIL_XY(128) }
+        if (box_.ny == 512) { MIL_XY(512) }
+        else if (box_.ny == 256) { MIL_XY(256) }
+        else { MIL_XY(128) }
 #undef MIL_XY
+    });
     MIL_HIP(hipGetLastError());
 }
 

@@ -188,11 +188,12 @@ __device__ __forceinline__ void dft_small(float2 *v) {
 // One radix-R pass over sub-transforms of length L of an N x 16 tile.
 //   DIF: y_k = w_L^(i*k) * DFT_R(x)[k]      DIT: y = DFT_R( w_L^(i*k) * x_k )
 // Lane mapping: column fastest (16 lanes), then butterfly index.
-// SKEW16: position p lives at tile[p * WP + (p >> 4) + column] (csrc/fft2p.hip: keeps accesses that step through the
-// positions 16 at a time off a single pair of banks); only for stages whose R elements share p >> 4 (L = 16).
-template <int N, int R, int L, bool DIT, int SIGN, int W = kW, int NT = kNT, int WP = W + 1, bool SKEW16 = false>
+// SKEW > 0: position p lives at tile[p * WP + p / SKEW + column] (csrc/fft2p.hip: keeps accesses that step through the
+// positions SKEW at a time off a single pair of banks); only for stages whose sub-transforms do not straddle a skew period
+// (L <= SKEW, SKEW a multiple of L).
+template <int N, int R, int L, bool DIT, int SIGN, int W = kW, int NT = kNT, int WP = W + 1, int SKEW = 0>
 __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float2 *__restrict__ tw) {
-    static_assert(!SKEW16 || (L == 16 && R == 16), "fft_stage: the skewed layout is only wired for the radix-16 stage of length 16");
+    static_assert(SKEW == 0 || (L <= SKEW && SKEW % L == 0), "fft_stage: a sub-transform must stay inside one skew period");
     constexpr int M = L / R;            // butterflies per sub-transform
     constexpr int NB = (N / R) * W;     // butterflies in the tile
     constexpr int TWS = N / L;          // table step: w_L = w_N^(N/L)
@@ -203,7 +204,7 @@ __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float
         const int c = idx % W;
         const int b = idx / W;
         const int blk = b / M, i = b % M;
-        float2 *p = tile + (blk * L + i) * WP + c + (SKEW16 ? blk : 0);
+        float2 *p = tile + (blk * L + i) * WP + c + (SKEW ? (blk * L) / SKEW : 0);
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = p[j * M * WP];
