@@ -18,11 +18,12 @@
 // the real-space operation).  Every column length of this library
 // starts its in-place transform with TWO radix-8 stages (fft_dev.h, pick_radix), so for any ny the "head" is 64 rows
 // y = n2 + T m (T = ny / 64) and the "tail" a transform of length T over T ADJACENT rows:
-//   xy_kernel<MODE, NY>      NY = 512, 256, 128 (T = 8, 4, 2): 64 rows of one plane per thread; does not care about z
+//   xy_kernel<MODE, NY>      NY = 1024, 512, 256, 128 (T = 16, 8, 4, 2): 64 rows of one plane per thread; does not care about z
 //   yz_conv_kernel           ny = 512, nz = 256: register tiles
-//   yz_lds_kernel<NY, NZ>    T x nz <= 1024: the tile of T rows x 16 columns x all z (<= 128 KB) FITS the LDS and the same
-//                            sequence runs on the classic LDS stage code
-// => {256, 512, 1024} x {512, 256, 128} x {64, 128, 256} (x, y, z) and ... x 128 x 512: 30 boxes.
+//   yz_lds_kernel<NY, NZ>    the tile of T rows x 16 columns x all z FITS the LDS (T x nz <= 1024; ny = 1024, nz = 128: 8-column
+//                            tiles) and the same sequence runs on the classic LDS stage code
+// => {256, 512, 1024} x {1024, 512, 256, 128} x {64, 128, 256} (x, y, z) without ... x 1024 x 256, and ... x 128 x 512:
+// 36 boxes.
 #include "fftconv.h"
 
 #include <cstddef>
@@ -68,16 +69,43 @@ __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned vo
 // One table per y extent: engines of different boxes may live on the same device (host threads), and each writes only
 // its own table -- with the same values every time.
 struct TwYTables {
-    float2 w128[128], w256[256], w512[512];
+    float2 w128[128], w256[256], w512[512], w1024[1024];
 };
 __constant__ TwYTables c_tw_y;
 __constant__ float2 c_tw_z[kNZ];
 template <int NY>
 __device__ __forceinline__ const float2 *tw_y_const() {
-    static_assert(NY == 128 || NY == 256 || NY == 512, "two-pass path: y extent");
+    static_assert(NY == 128 || NY == 256 || NY == 512 || NY == 1024, "two-pass path: y extent");
     if constexpr (NY == 128) return c_tw_y.w128;
     else if constexpr (NY == 256) return c_tw_y.w256;
-    else return c_tw_y.w512;
+    else if constexpr (NY == 512) return c_tw_y.w512;
+    else return c_tw_y.w1024;
+}
+
+// The y tail: the in-place transform of length T = NY / 64 over T adjacent rows.  For T <= 8 it is one radix-T stage
+// (natural order); for T = 16 the classic schedule is radix 8 then radix 2, which leaves frequency f = k1 + 8 k2 at row
+// 2 k1 + k2.  tail_forward: rows in natural order -> frequencies at their classic positions; tail_inverse: the reverse.
+template <int T>
+__device__ __forceinline__ int tail_pos(int f) {
+    return T == 16 ? 2 * (f & 7) + (f >> 3) : f;
+}
+template <int T>
+__device__ __forceinline__ void tail_forward(float2 *p, int stride) {
+    float2 t[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) t[k] = p[k * stride];
+    dft_small<T, -1>(t);
+#pragma unroll
+    for (int k = 0; k < T; ++k) p[tail_pos<T>(k) * stride] = t[k];
+}
+template <int T>
+__device__ __forceinline__ void tail_inverse(float2 *p, int stride) {
+    float2 t[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) t[k] = p[tail_pos<T>(k) * stride];
+    dft_small<T, +1>(t);
+#pragma unroll
+    for (int k = 0; k < T; ++k) p[k * stride] = t[k];
 }
 
 
@@ -156,27 +184,20 @@ __device__ __forceinline__ float2 swap_pair(float2 a) {
 template <int NY, int NZ, int NH>
 __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *tile, const float2 *tw, int pair) {
     constexpr int T = NY / 64, C = 2 * T;  // rows per block, columns of the tile in use
+    constexpr int PW = C > kW ? C : kW, PWP = PW + 1;  // tile[z][PW + 1]
     constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
     const int tid = threadIdx.x;
     const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
     for (int i = tid; i < NZ * C; i += kYzThreads) {
         const int c = i % C, z = i / C;
-        tile[z * kWP + c] = a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch];
+        tile[z * PWP + c] = a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch];
     }
-    if (C < kW)  // the z stages below run over all 16 columns of the tile: keep the unused ones finite
-        for (int i = tid; i < NZ * (kW - C); i += kYzThreads) tile[(i / (kW - C)) * kWP + C + i % (kW - C)] = make_float2(0.f, 0.f);
+    if (C < PW)  // the z stages below run over all PW columns of the tile: keep the unused ones finite
+        for (int i = tid; i < NZ * (PW - C); i += kYzThreads) tile[(i / (PW - C)) * PWP + C + i % (PW - C)] = make_float2(0.f, 0.f);
     lds_barrier();
-    for (int i = tid; i < NZ * 2; i += kYzThreads) {
-        float2 *p = tile + (i >> 1) * kWP + T * (i & 1);
-        float2 t[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) t[k] = p[k];
-        dft_small<T, -1>(t);
-#pragma unroll
-        for (int k = 0; k < T; ++k) p[k] = t[k];
-    }
+    for (int i = tid; i < NZ * 2; i += kYzThreads) tail_forward<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
     lds_barrier();
-    fft_dif<NZ, NZ, -1, kW, kYzThreads, kWP>(tile, tw);
+    fft_dif<NZ, NZ, -1, PW, kYzThreads, PWP>(tile, tw);
     constexpr int PER = (NZ * C + kYzThreads - 1) / kYzThreads;
     float2 r[PER];
 #pragma unroll
@@ -186,7 +207,7 @@ __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *til
             const int row = T * blk[c / T] + (c % T);
             const int prow = a.neg_y[row];
             const int pc = ((prow / T) == blk[0] ? 0 : T) + (prow % T);
-            const float2 gk = tile[p * kWP + c], gp = tile[a.neg_z[p] * kWP + pc];
+            const float2 gk = tile[p * PWP + c], gp = tile[a.neg_z[p] * PWP + pc];
             const float2 pv = a.otf[(((long long)row * kGroups) * NZ + p) * kW];
             const float2 qv = a.otf_q[(long long)row * NZ + p];
             r[i] = c_add(c_mul(gk, pv), c_mul(qv, make_float2(gp.x, -gp.y)));
@@ -196,24 +217,16 @@ __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *til
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = i * kYzThreads + tid;
-        if (e < NZ * C) tile[(e / C) * kWP + (e % C)] = r[i];
+        if (e < NZ * C) tile[(e / C) * PWP + (e % C)] = r[i];
     }
     lds_barrier();
-    fft_dit<NZ, NZ, +1, kW, kYzThreads>(tile, tw);
-    for (int i = tid; i < NZ * 2; i += kYzThreads) {
-        float2 *p = tile + (i >> 1) * kWP + T * (i & 1);
-        float2 t[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) t[k] = p[k];
-        dft_small<T, +1>(t);
-#pragma unroll
-        for (int k = 0; k < T; ++k) p[k] = t[k];
-    }
+    fft_dit<NZ, NZ, +1, PW, kYzThreads>(tile, tw);
+    for (int i = tid; i < NZ * 2; i += kYzThreads) tail_inverse<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
     lds_barrier();
     const int ncol = (blk[0] == blk[1]) ? T : C;
     for (int i = tid; i < NZ * C; i += kYzThreads) {
         const int c = i % C, z = i / C;
-        if (c < ncol) a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch] = tile[z * kWP + c];
+        if (c < ncol) a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch] = tile[z * PWP + c];
     }
 }
 
@@ -407,20 +420,22 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// yz_conv where the tile fits the LDS (T x NZ <= 1024, T = NY / 64 rows of the y tail): T rows x 16 columns x NZ z =
-// T * NZ / 8 KB + padding, so the same sequence
+// yz_conv where the tile fits the LDS: T rows (T = NY / 64, the y tail) x COLS columns x NZ z <= 16384 complex = 128 KB
+// + padding -- COLS = 16 (128-byte row segments) for T x NZ <= 1024, 8 or 4 columns for the taller boxes -- so the sequence
 //   y tail(T) . z . OTF . z^-1 . y tail(T)^-1
 // runs on tile[z][T rows x 16 columns] with the classic LDS stage code, T * 16 "columns" per z position.  One trip of the
 // spectrum through HBM (3 C'') where the classic kernels make three (y tail | z-conv | y tail^-1: 7 C'').
 // ---------------------------------------------------------------------------
-template <int NY, int NZ, int NH>
+template <int NY, int NZ, int NH, int COLS>
 __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
     constexpr int T = NY / 64;
+    // COLS columns per tile: 16 (128-byte row segments) wherever T x NZ x 16 complex fit the LDS, else 8 or 4
+    static_assert(T * NZ * COLS <= 16384 && (COLS == 16 || COLS == 8 || COLS == 4), "yz_lds_kernel: tile does not fit the LDS");
     constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
-    static_assert(T * NZ <= 1024 && (T == 2 || T == 4 || T == 8), "yz_lds_kernel: tile does not fit the LDS");
-    constexpr int W = T * kW, WP = W + 1;  // row r, column c of the block sit at "column" r * 16 + c
-    constexpr int QR = kW / 2;             // float4 pieces per 128-byte row segment
-    __shared__ float2 tile[NZ * WP > NZ * kWP ? NZ * WP : NZ * kWP];
+    constexpr int W = T * COLS, WP = W + 1;  // row r, column c of the block sit at "column" r * COLS + c
+    constexpr int QR = COLS / 2;             // float4 pieces per row segment
+    constexpr int PWP = (2 * T > kW ? 2 * T : kW) + 1;  // packed_column_block's tile
+    __shared__ float2 tile[NZ * WP > NZ * PWP ? NZ * WP : NZ * PWP];
     __shared__ float2 tw[NZ];
     const int tid = threadIdx.x;
     for (int k = tid; k < NZ; k += kYzThreads) tw[k] = tw_z[k];
@@ -429,11 +444,13 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
         packed_column_block<NY, NZ, NH>(a, tile, tw, (int)blockIdx.x);
         return;
     }
+    constexpr int GROUPS = NH / COLS;
     const int tile_id = blockIdx.x - a.pair_blocks;
-    const int g = tile_id % kGroups, b = tile_id / kGroups;
-    float2 *base = a.S + (long long)(T * b) * kPitch + g * kW;
+    const int g = tile_id % GROUPS, b = tile_id / GROUPS;
+    const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // the 16-column group of the OTF tiling, offset inside it
+    float2 *base = a.S + (long long)(T * b) * kPitch + g * COLS;
     constexpr long long zstride = (long long)NY * kPitch;
-    // ---- load: NZ x T row segments of 128 bytes
+    // ---- load: NZ x T row segments
     constexpr int TOTAL = NZ * T * QR;  // float4 pieces
 #pragma unroll 1
     for (int it0 = 0; it0 < TOTAL; it0 += kYzThreads * kBatch) {
@@ -449,7 +466,7 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
             const int idx = it0 + j * kYzThreads + tid;
             const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
             if (idx < TOTAL) {
-                float2 *p = tile + z * WP + row * kW + 2 * q;
+                float2 *p = tile + z * WP + row * COLS + 2 * q;
                 p[0] = make_float2(v[j].x, v[j].y);
                 p[1] = make_float2(v[j].z, v[j].w);
             }
@@ -457,18 +474,10 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
     }
     lds_barrier();
     // ---- y tail: the transform of length T over the rows of every (z, column)
-    for (int i = tid; i < NZ * kW; i += kYzThreads) {
-        float2 *p = tile + (i / kW) * WP + (i % kW);
-        float2 t[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) t[k] = p[k * kW];
-        dft_small<T, -1>(t);
-#pragma unroll
-        for (int k = 0; k < T; ++k) p[k * kW] = t[k];
-    }
+    for (int i = tid; i < NZ * COLS; i += kYzThreads) tail_forward<T>(tile + (i / COLS) * WP + (i % COLS), COLS);
     lds_barrier();
     fft_dif<NZ, NZ, -1, W, kYzThreads, WP>(tile, tw);
-    // ---- OTF product: the classic tiling [row][16-column group][kz][16]: one contiguous [NZ][16] block per row
+    // ---- OTF product: the classic tiling [row][16-column group][kz][16]
     {
         constexpr int PIECES = T * NZ * QR;  // float4 pieces
 #pragma unroll 1
@@ -479,14 +488,14 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
                 const int idx = it0 + j * kYzThreads + tid;
                 const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
                 if (idx < PIECES)
-                    v[j] = *reinterpret_cast<const float4 *>(a.otf + ((((long long)(T * b + row) * kGroups + g) * NZ + kz) * kW) + 2 * q);
+                    v[j] = *reinterpret_cast<const float4 *>(a.otf + ((((long long)(T * b + row) * kGroups + g16) * NZ + kz) * kW) + c16 + 2 * q);
             }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 const int idx = it0 + j * kYzThreads + tid;
                 const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
                 if (idx < PIECES) {
-                    float2 *p = tile + kz * WP + row * kW + 2 * q;
+                    float2 *p = tile + kz * WP + row * COLS + 2 * q;
                     p[0] = c_mul(p[0], make_float2(v[j].x, v[j].y));
                     p[1] = c_mul(p[1], make_float2(v[j].z, v[j].w));
                 }
@@ -495,21 +504,13 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
     }
     lds_barrier();
     fft_dit<NZ, NZ, +1, W, kYzThreads>(tile, tw);
-    for (int i = tid; i < NZ * kW; i += kYzThreads) {
-        float2 *p = tile + (i / kW) * WP + (i % kW);
-        float2 t[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) t[k] = p[k * kW];
-        dft_small<T, +1>(t);
-#pragma unroll
-        for (int k = 0; k < T; ++k) p[k * kW] = t[k];
-    }
+    for (int i = tid; i < NZ * COLS; i += kYzThreads) tail_inverse<T>(tile + (i / COLS) * WP + (i % COLS), COLS);
     lds_barrier();
     // ---- store; the packed column (group 0, column 0) belongs to the pair blocks
 #pragma unroll 4
     for (int idx = tid; idx < TOTAL; idx += kYzThreads) {
         const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
-        const float2 *p = tile + z * WP + row * kW + 2 * q;
+        const float2 *p = tile + z * WP + row * COLS + 2 * q;
         float2 *dst = base + z * zstride + (long long)row * kPitch + 2 * q;
         if (g == 0 && q == 0) dst[1] = p[1];
         else *reinterpret_cast<float4 *>(dst) = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
@@ -759,10 +760,14 @@ unsigned long long *g_stamps = nullptr;  // set through mil_fx_set_stamps (timin
 
 bool ConvPlan::two_pass_supported(Dims b) {
     if (b.nx != 256 && b.nx != 512 && b.nx != 1024) return false;
-    if (b.ny != 512 && b.ny != 256 && b.ny != 128) return false;
+    if (b.ny != 1024 && b.ny != 512 && b.ny != 256 && b.ny != 128) return false;
     const long long t = b.ny / 64;
     if (b.ny == kNY && b.nz == kNZ) return true;                              // register yz kernel
-    return (b.nz == 64 || b.nz == 128 || b.nz == 256 || b.nz == 512) && t * b.nz <= 1024;  // LDS-resident yz kernel
+    if (b.nz != 64 && b.nz != 128 && b.nz != 256 && b.nz != 512) return false;
+    // ny = 1024: LDS-resident yz kernel on 16- / 8-column tiles.  nz = 256 would need 4-column tiles (32-byte row segments):
+    // measured SLOWER than the classic sequence (1024 x 1024 x 256: 172 against 201 it/s, profiles/r03/bench_box_ny1024.txt)
+    if (b.ny == 1024) return b.nz <= 128;
+    return t * b.nz <= 1024;               // LDS-resident yz kernel, 16-column tiles
 }
 
 void ConvPlan::init_two_pass() {
@@ -784,7 +789,8 @@ void ConvPlan::init_two_pass() {
     {
         std::vector<float2> ty((size_t)ny);
         MIL_HIP(hipMemcpy(ty.data(), tw_y_.get(), ty.size() * sizeof(float2), hipMemcpyDeviceToHost));
-        const size_t off = ny == 128 ? offsetof(TwYTables, w128) : ny == 256 ? offsetof(TwYTables, w256) : offsetof(TwYTables, w512);
+        const size_t off = ny == 128 ? offsetof(TwYTables, w128) : ny == 256 ? offsetof(TwYTables, w256)
+                         : ny == 512 ? offsetof(TwYTables, w512) : offsetof(TwYTables, w1024);
         MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_y), ty.data(), ty.size() * sizeof(float2), off));
         if (ny == kNY && box_.nz == kNZ) {  // the register yz kernel reads its z twiddles from constant memory
             std::vector<float2> tz((size_t)kNZ);
@@ -823,7 +829,8 @@ void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
         case 2: hipLaunchKernelGGL((col_part_kernel<N, NT, 2>), grid, dim3(NT), 0, s, a); break;               \
         default: hipLaunchKernelGGL((col_part_kernel<N, NT, 3>), grid, dim3(NT), 0, s, a); break;              \
     }
-    if (box_.ny == 512) { MIL_PART(512, 512) }
+    if (box_.ny == 1024) { MIL_PART(1024, 512) }
+    else if (box_.ny == 512) { MIL_PART(512, 512) }
     else if (box_.ny == 256) { MIL_PART(256, 256) }
     else { MIL_PART(128, 256) }
 #undef MIL_PART
@@ -837,24 +844,27 @@ void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     a.neg_y = neg_y_.get(); a.neg_z = neg_z_.get(); a.pairs = pairs_.get();
     a.pair_blocks = n_pairs_;
     a.stamps = g_stamps;
-    const dim3 grid((unsigned)(64 * (xs_ / kW) + n_pairs_)), block(kYzThreads);  // 64 blocks of T rows, whatever ny is
+    const dim3 block(kYzThreads);
+    auto grid_for = [&](int cols) { return dim3((unsigned)(64 * (xs_ / cols) + n_pairs_)); };  // 64 blocks of T rows, whatever ny is
     const float2 *twz = tw_z_.get();
     const int ny = (int)box_.ny, nz = (int)box_.nz;
     // (8-column tiles -- 64-byte segments, two workgroups per CU at 512 x 512 x 128 -- measured: 2 200 against 2 170 it/s,
     // within noise, profiles/r03/bench_box_nz128.txt; the 16-column form stays)
     with_nh(box_.nx, [&](auto nh_tag) {
         constexpr int NH = decltype(nh_tag)::value;
-#define MIL_YZ(NY, NZ) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ, NH>), grid, block, 0, s, a, twz)
-        if (ny == kNY && nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel<NH>, grid, block, 0, s, a);
-        else if (ny == 512 && nz == 128) MIL_YZ(512, 128);
-        else if (ny == 512 && nz == 64) MIL_YZ(512, 64);
-        else if (ny == 256 && nz == 256) MIL_YZ(256, 256);
-        else if (ny == 256 && nz == 128) MIL_YZ(256, 128);
-        else if (ny == 256 && nz == 64) MIL_YZ(256, 64);
-        else if (ny == 128 && nz == 512) MIL_YZ(128, 512);
-        else if (ny == 128 && nz == 256) MIL_YZ(128, 256);
-        else if (ny == 128 && nz == 128) MIL_YZ(128, 128);
-        else if (ny == 128 && nz == 64) MIL_YZ(128, 64);
+#define MIL_YZ(NY, NZ, COLS) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ, NH, COLS>), grid_for(COLS), block, 0, s, a, twz)
+        if (ny == kNY && nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel<NH>, grid_for(kW), block, 0, s, a);
+        else if (ny == 1024 && nz == 128) MIL_YZ(1024, 128, 8);
+        else if (ny == 1024 && nz == 64) MIL_YZ(1024, 64, 16);
+        else if (ny == 512 && nz == 128) MIL_YZ(512, 128, 16);
+        else if (ny == 512 && nz == 64) MIL_YZ(512, 64, 16);
+        else if (ny == 256 && nz == 256) MIL_YZ(256, 256, 16);
+        else if (ny == 256 && nz == 128) MIL_YZ(256, 128, 16);
+        else if (ny == 256 && nz == 64) MIL_YZ(256, 64, 16);
+        else if (ny == 128 && nz == 512) MIL_YZ(128, 512, 16);
+        else if (ny == 128 && nz == 256) MIL_YZ(128, 256, 16);
+        else if (ny == 128 && nz == 128) MIL_YZ(128, 128, 16);
+        else if (ny == 128 && nz == 64) MIL_YZ(128, 64, 16);
         else throw Error(-1, "yz_conv: box outside the two-pass path");
 #undef MIL_YZ
     });
@@ -881,7 +891,8 @@ void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float ep
         case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate, NY, NH>), grid, block, 0, s, a); break;           \
         default: hipLaunchKernelGGL((xy_kernel<kXUpdateLast, NY, NH>), grid, block, 0, s, a); break;             \
     }
-        if (box_.ny == 512) { MIL_XY(512) }
+        if (box_.ny == 1024) { MIL_XY(1024) }
+        else if (box_.ny == 512) { MIL_XY(512) }
         else if (box_.ny == 256) { MIL_XY(256) }
         else { MIL_XY(128) }
 #undef MIL_XY

@@ -125,7 +125,8 @@ def test_backends_agree_at_benchmark_size(dev):
         assert err < 1e-5, ("single" if k == 0 else "dual", err)
 
 
-_YZ = [(256, 512), (128, 512), (64, 512),                 # (nz, ny): y tail T = ny / 64 = 8
+_YZ = [(128, 1024), (64, 1024),                           # (nz, ny): y tail T = ny / 64 = 16 (8-, 16-column yz tiles)
+       (256, 512), (128, 512), (64, 512),                 # T = 8
        (256, 256), (128, 256), (64, 256),                 # T = 4
        (512, 128), (256, 128), (128, 128), (64, 128)]     # T = 2
 TWO_PASS_BOXES = [(nz, ny, nx) for nx in (512, 256, 1024) for (nz, ny) in _YZ]  # (nz, ny, nx)
@@ -133,8 +134,8 @@ TWO_PASS_BOXES = [(nz, ny, nx) for nx in (512, 256, 1024) for (nz, ny) in _YZ]  
 
 @pytest.mark.parametrize("shape", TWO_PASS_BOXES, ids=lambda s: "x".join(str(v) for v in s[::-1]))
 def test_two_pass_kernels_agree_with_the_classic_sequence(dev, monkeypatch, shape):
-    """csrc/fft2p.hip on every box it covers (nx = 256 / 512 / 1024 = x transforms of 16 x 8 / 16 / 32; ny = 512 / 256 / 128
-    = y tails of 8 / 4 / 2 rows; every nz whose yz tile fits the LDS, plus ... x 512 x 256 on register tiles): the yz kernel
+    """csrc/fft2p.hip on every box it covers (nx = 256 / 512 / 1024 = x transforms of 16 x 8 / 16 / 32; ny = 1024 / 512 / 256 /
+    128 = y tails of 16 / 8 / 4 / 2 rows; every nz whose yz tile fits the LDS, plus ... x 512 x 256 on register tiles): the yz kernel
     alone (MIL_FX_TWOPASS=1, partial classic y
     passes around it), the xy kernel alone (2) and both (3, the default on these boxes) against the classic four-kernel
     half update (0) -- 3 single-view and 2 dual-view iterations on the same inputs, the last one through the

@@ -11,7 +11,7 @@ def gaussian_psf(shape, sig):
     g = [np.exp(-0.5 * ((np.arange(s) - s // 2) / sg) ** 2) for s, sg in zip(shape, sig)]
     return (g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
 
-BOXES = [(64, 64, 64), (128, 128, 128), (128, 256, 256), (256, 256, 256), (64, 512, 512), (128, 512, 512), (256, 512, 512), (64, 256, 512), (128, 256, 512), (256, 256, 512), (64, 128, 512), (128, 128, 512), (256, 128, 512), (512, 128, 512), (256, 512, 256), (128, 512, 256), (256, 512, 1024), (128, 512, 1024), (64, 512, 1024), (256, 256, 1024), (512, 512, 512), (192, 192, 192), (256, 384, 384), (128, 320, 448), (256, 576, 640), (512, 1024, 1024)]
+BOXES = [(64, 64, 64), (128, 128, 128), (128, 256, 256), (256, 256, 256), (64, 512, 512), (128, 512, 512), (256, 512, 512), (64, 256, 512), (128, 256, 512), (256, 256, 512), (64, 128, 512), (128, 128, 512), (256, 128, 512), (512, 128, 512), (256, 512, 256), (128, 512, 256), (256, 512, 1024), (128, 512, 1024), (64, 512, 1024), (256, 256, 1024), (64, 1024, 1024), (128, 1024, 1024), (256, 1024, 1024), (256, 1024, 512), (512, 512, 512), (192, 192, 192), (256, 384, 384), (128, 320, 448), (256, 576, 640), (512, 1024, 1024)]
 iters = 10
 rows = []
 for box in BOXES:
