@@ -110,7 +110,9 @@ def main():
     # first 5 steps after idle, 1.02 ms after 50, 1.01 ms after 100).  A fixed number of untimed steps before the W
     # warm-up steps brings it to the sustained state a long deconvolution runs in, whatever W the caller picks.
     ap.add_argument("--clock-warm-steps", type=int, default=50)
-    ap.add_argument("--batch-time-points-per-gpu", type=int, default=2,
+    ap.add_argument("--batch-lanes", type=int, default=2,
+                    help="time points in flight per GPU in the config-5 figure (host threads, batch.run_sharded(lanes=))")
+    ap.add_argument("--batch-time-points-per-gpu", type=int, default=4,
                     help="time points per GPU of the config-5 figure in `extra` (register + joint RL + MIP); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -357,13 +359,21 @@ def main():
         known2 = np.concatenate([lin2, (centre2 - lin2 @ centre2 + np.array([3.0, -2.0, 1.0]))[:, None]],
                                 axis=1).astype(np.float32).reshape(12)
         view_b = mdev.affine_resample(synth_volume(torch, SHAPE, (2.5, 2.5, 6.0), seed=100 + rank), known2, SHAPE)  # same object as view A, other PSF, displaced by 2 deg + shift
-        pipe = batch.FusionPipeline(SHAPE, psf_a, psf_b, iters=20)
+        lanes = max(1, args.batch_lanes)
+        pipes = [batch.FusionPipeline(SHAPE, psf_a, psf_b, iters=20) for _ in range(lanes)]
+        pipe = pipes[0]
         n_tp = args.batch_time_points_per_gpu * world
         pol = lambda: batch.RegPolicy(reg_mode=3, reg_choice=2, aff_method=6, ftol=1e-4, it_limit=3000)
-        # overlap: the joint RL of time point i runs on a helper thread / its own stream while i + 1 is registered
-        run = lambda tps: batch.run_sharded(tps, lambda t: (img_a, view_b), pipe.fuse_pair, pol(), pipe.reg_fn,
-                                            pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev, overlap=True)
-        run(list(range(world)))  # warm-up: one time point per rank
+        if lanes > 1:
+            # `lanes` time points in flight per GPU, one host thread each with its own engine: the kernels of one fill the
+            # host round trips between the dependent cost evaluations of the other
+            run = lambda tps: batch.run_sharded(tps, lambda t: (img_a, view_b), [p.fuse_pair for p in pipes], pol(),
+                                                pipe.reg_fn, pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev, lanes=lanes)
+        else:
+            # overlap: the joint RL of time point i runs on a helper thread / its own stream while i + 1 is registered
+            run = lambda tps: batch.run_sharded(tps, lambda t: (img_a, view_b), pipe.fuse_pair, pol(), pipe.reg_fn,
+                                                pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev, overlap=True)
+        run(list(range(world * lanes)))  # warm-up: one time point per lane and rank
         fence()
         tb = time.perf_counter()
         stack = run(list(range(n_tp)))
@@ -378,9 +388,10 @@ def main():
                 "workload": "spimFusionBatch loop, regMode 3: reg3d (affMethod 6) + joint dual-view RL (20 it) + XY MIP per "
                             "time point, 512x512x256, views resident in HBM, MIP stack gathered to rank 0",
                 "time_points": n_tp, "time_points_per_s": round(n_tp / batch_s, 3), "elapsed_s": round(batch_s, 3),
-                "mip_stack": list(stack.shape)}
-        pipe.close()
-        del view_b, pipe
+                "time_points_in_flight_per_gpu": lanes, "mip_stack": list(stack.shape)}
+        for p in pipes:
+            p.close()
+        del view_b, pipe, pipes
 
     # ---- supplementary: dual view + registration (N = 1 only) ---------------------------
     if world == 1 and not args.no_extra:

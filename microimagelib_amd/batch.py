@@ -145,7 +145,7 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
                 fuse_pair: Callable[[object, object, int], Tuple[object, torch.Tensor]],
                 policy: RegPolicy, reg_fn: RegFn, check_fn: CheckFn, mip_shape: Tuple[int, int],
                 sink: Optional[Callable[[int, object, np.ndarray, np.ndarray], None]] = None,
-                device="cpu", group=None, overlap: bool = False) -> Optional[torch.Tensor]:
+                device="cpu", group=None, overlap: bool = False, lanes: int = 1) -> Optional[torch.Tensor]:
     """Run the batch over this rank's share of `time_points`.
 
     load_pair(t) -> (view A, view B) already resized / rotated; fuse_pair(A, B_registered, t) -> (decon, XY MIP);
@@ -160,6 +160,12 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
     reads b_reg of i while i + 1 is registered).  fuse_pair may reuse one output buffer: one deconvolution is in flight at
     a time and its MIP is cloned before the next starts.  Results are the same, only the order of host-side side effects
     within a rank changes.  Modes 0, 1, 3.
+    lanes > 1 (modes 0, 1, 3): this rank works on `lanes` time points AT ONCE, one host thread each -- the same idea as the
+    command-line tool's worker threads (cli/spim_fusion_batch_main.cpp: a device listed twice).  A registration is a chain
+    of ~10^3 dependent cost evaluations with a host round trip between any two, so one time point alone leaves the GPU idle
+    in the gaps; a second time point's kernels fill them.  `fuse_pair` must then be a SEQUENCE of `lanes` callables (each
+    with its own engine / estimate buffer: FusionPipeline per lane); `load_pair`, `reg_fn`, `check_fn` and `sink` are
+    called from several threads.  Every time point is processed exactly as with one lane: same results.
     Returns the time-ordered MIP stack on rank 0."""
     rank, world = _world(group)
     time_points = list(time_points)
@@ -176,6 +182,33 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
         policy = RegPolicy(reg_mode=0, reg_choice=0, aff_method=policy.aff_method, ftol=policy.ftol,
                            it_limit=policy.it_limit, cost_bar=policy.cost_bar, i_tmx=tmx)
     local: Dict[int, torch.Tensor] = {}
+    if lanes > 1:
+        if policy.reg_mode == 2:
+            raise ValueError("lanes > 1 needs independent time points (regMode 0, 1 or 3)")
+        fuse_list = list(fuse_pair)
+        if len(fuse_list) != lanes:
+            raise ValueError("lanes > 1: fuse_pair must be a sequence of one callable per lane")
+        import concurrent.futures
+        import dataclasses
+        mine = shard_time_points(time_points, rank, world)
+        dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def lane(l):
+            if dev_index is not None:
+                torch.cuda.set_device(dev_index)  # the current device is per thread
+            pol = dataclasses.replace(policy)
+            for j, t in enumerate(mine[l::lanes]):
+                a, b = load_pair(t)
+                b_reg, tmx, rec = register_pair(pol, reg_fn, check_fn, a, b, first=(j == 0))
+                decon, mip = fuse_list[l](a, b_reg, t)
+                local[t] = mip.clone()
+                if sink is not None:
+                    sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=lanes) as pool:
+            for f in [pool.submit(lane, l) for l in range(lanes)]:
+                f.result()
+        return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
 
     def finish(a, b_reg, t, tmx, rec):
         decon, mip = fuse_pair(a, b_reg, t)

@@ -233,3 +233,45 @@ def test_chained_mode_running_average_single_rank():
                               reg_fn, lambda m: True, MIP_SHAPE)
     assert stack.shape == (3, *MIP_SHAPE)
     assert starts[0] is None and starts[1] == 10.0 and abs(starts[2] - (0.8 * 10 + 0.2 * 20)) < 1e-5
+
+
+def test_lanes_process_time_points_concurrently_with_the_same_results():
+    """run_sharded(lanes=2): two time points in flight per rank, one host thread each, each with its own fuse callable;
+    matrices, sinks and the MIP stack are those of the one-lane run."""
+    import threading
+    tps = list(range(20, 31))
+    results = {}
+    for lanes in (1, 2, 3):
+        log, sunk, seen_threads = [], {}, set()
+        lock = threading.Lock()
+
+        def reg_fn(target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
+            tmx = np.zeros(12, dtype=np.float32)
+            tmx[[0, 5, 10]] = 1
+            tmx[3] = float(target) * 0.5
+            rec = np.zeros(11, dtype=np.float32)
+            rec[3] = 0.9
+            with lock:
+                log.append(int(target))
+                seen_threads.add(threading.get_ident())
+            import time
+            time.sleep(0.002)  # long enough for the lanes to overlap
+            return source, tmx, rec
+
+        def make_fuse(l):
+            def fuse(a, b_reg, t):
+                return None, torch.full(MIP_SHAPE, float(10 * t + 1))
+            return fuse
+
+        def sink(t, decon, tmx, rec):
+            with lock:
+                sunk[t] = tmx.tolist()
+
+        fuse = make_fuse(0) if lanes == 1 else [make_fuse(l) for l in range(lanes)]
+        stack = batch.run_sharded(tps, lambda t: (t, t), fuse, batch.RegPolicy(reg_mode=3, reg_choice=2), reg_fn,
+                                  lambda m: True, MIP_SHAPE, sink=sink, lanes=lanes)
+        assert sorted(log) == tps and 1 <= len(seen_threads) <= lanes
+        results[lanes] = (stack[:, 0, 0].tolist(), sunk)
+    assert results[1] == results[2] == results[3]
+    with pytest.raises(ValueError):
+        batch.run_sharded(tps, lambda t: (t, t), [None, None], batch.RegPolicy(reg_mode=2), None, None, MIP_SHAPE, lanes=2)

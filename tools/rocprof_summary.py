@@ -21,7 +21,7 @@ OURS = {  # kernel-name pattern -> bench.py family key (config size 512x512x256)
     "fused": {r"x_kernel<256, 3,": "x_update", r"x_kernel<256, 2,": "x_ratio", r"col_kernel<512, 512, [01]>": "y_pass",
               r"col_kernel<256, 256, 2>": "z_conv",
               # two passes per convolution (csrc/fft2p.hip)
-              r"yz_conv_kernel": "yz_conv", r"xy_kernel<2>": "xy_ratio", r"xy_kernel<3>": "xy_update"},
+              r"yz_conv_kernel": "yz_conv", r"xy_kernel<2(, 512, 256)?>": "xy_ratio", r"xy_kernel<3(, 512, 256)?>": "xy_update"},
     "rocfft": {r"ew_inplace2_kernel<.*UpdateOp": "rl_update", r"ew_inplace2_kernel<.*RatioOp": "rl_ratio",
                r"cmul_kernel": "cmul_otf"},
 }
@@ -71,6 +71,20 @@ def main(src, dst):
                 for k, v in per.items():
                     if re.search(pat, k):
                         traffic.setdefault(backend, {})[key] = v["hbm_bytes_per_launch"]
+        # provenance: bench.py drops `traffic` when a kernel source changed after this measurement
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import bench
+        traffic["sources_sha256"] = bench.kernel_source_hashes()
+        traffic["commit"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                           text=True).stdout.strip() or None
+        symbols = traffic.setdefault("symbols", {})
+        for backend, pats in OURS.items():
+            for pat, key in pats.items():
+                for k in per:
+                    if re.search(pat, k):
+                        symbols[key] = k
         traffic["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py at 512x512x256; "
                              "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE correction, "
                              "MI355X_MICROARCH.md)")
