@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--host", action="store_true", help="views in pinned host memory, result copied back")
     ap.add_argument("--overlap", action="store_true",
                     help="deconvolve time point i on a helper thread while time point i + 1 is registered (regModes 0, 1, 3)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="time points in flight per GPU, one host thread and engine each (batch.run_sharded lanes=; "
+                         "regModes 0, 1, 3; not with --tiff)")
     ap.add_argument("--tiff", metavar="DIR", default=None,
                     help="read both views of every time point from 16-bit TIFF stacks under DIR/rank<r>/ and write the "
                          "deconvolved stack there, inside the timed region (files are created before it)")
@@ -81,7 +84,10 @@ def main():
     base_b = mdev.affine_resample(base_b0, known, shape)
     del base_b0
 
-    pipe = batch.FusionPipeline(shape, psf_a, psf_b, iters=args.iters)
+    if args.lanes > 1 and (args.tiff or args.overlap or args.reg_mode == 2):
+        raise SystemExit("--lanes goes with views in HBM / pinned memory, regModes 0, 1, 3, without --overlap")
+    pipes = [batch.FusionPipeline(shape, psf_a, psf_b, iters=args.iters) for _ in range(max(1, args.lanes))]
+    pipe = pipes[0]
     split = {"load": 0.0, "register": 0.0, "fuse": 0.0, "store": 0.0}
     evals = []
     host_out = torch.empty(shape, dtype=torch.float32).pin_memory() if args.host else None
@@ -105,8 +111,8 @@ def main():
 
     load_stream = torch.cuda.Stream()
 
-    def dev_sync():  # per-phase seconds need a device-wide wait; with --overlap that would serialise the two threads
-        if not args.overlap:
+    def dev_sync():  # per-phase seconds need a device-wide wait; with --overlap / --lanes that would serialise the threads
+        if not args.overlap and args.lanes <= 1:
             torch.cuda.synchronize()
 
     def load_pair(t):
@@ -141,12 +147,15 @@ def main():
         evals.append(float(out[2][5]))
         return out
 
-    def fuse_pair(a, b, t):
-        t0 = time.perf_counter()
-        out = pipe.fuse_pair(a, b, t)
-        dev_sync()
-        split["fuse"] += time.perf_counter() - t0
-        return out
+    def make_fuse(p):
+        def fuse(a, b, t):
+            t0 = time.perf_counter()
+            out = p.fuse_pair(a, b, t)
+            dev_sync()
+            split["fuse"] += time.perf_counter() - t0
+            return out
+        return fuse
+    fuse_pair = make_fuse(pipe) if args.lanes <= 1 else [make_fuse(p) for p in pipes]
 
     def sink(t, decon, tmx, rec):
         t0 = time.perf_counter()
@@ -163,8 +172,8 @@ def main():
     policy = lambda: batch.RegPolicy(reg_mode=args.reg_mode, reg_choice=2, aff_method=6, ftol=1e-4, it_limit=3000,
                                      i_tmx=known if args.reg_mode == 0 else None)
     # warm-up: one time point per rank (plans, OTFs, clocks), not timed
-    batch.run_sharded(tps[:world], load_pair, fuse_pair, policy(), reg_fn, pipe.check_fn, (shape[1], shape[2]),
-                      sink=sink, device=coll_dev)
+    batch.run_sharded(tps[:world * max(1, args.lanes)], load_pair, fuse_pair, policy(), reg_fn, pipe.check_fn,
+                      (shape[1], shape[2]), sink=sink, device=coll_dev, lanes=max(1, args.lanes))
     for k in split:
         split[k] = 0.0
     evals.clear()
@@ -182,7 +191,7 @@ def main():
     batch.gather_mip_stack = timed_gather
     t0 = time.perf_counter()
     stack = batch.run_sharded(tps, load_pair, fuse_pair, policy(), reg_fn, pipe.check_fn, (shape[1], shape[2]),
-                              sink=sink, device=coll_dev, overlap=args.overlap)
+                              sink=sink, device=coll_dev, overlap=args.overlap, lanes=max(1, args.lanes))
     torch.cuda.synchronize()
     batch.gather_mip_stack = real_gather
     if world > 1:
@@ -199,6 +208,7 @@ def main():
             "value": round(args.time_points / elapsed, 3), "unit": "time points/s", "n_gpus": world,
             "time_points": args.time_points, "rl_iterations": args.iters, "reg_mode": args.reg_mode,
             "elapsed_s": round(elapsed, 3), "overlap_deconvolution_with_next_registration": bool(args.overlap),
+            "time_points_in_flight_per_gpu": max(1, args.lanes),
             "views": ("16-bit TIFF stacks on disk, read and written inside the timed region" if tiff_dir else
                       "pinned host memory" if args.host else "resident in HBM"),
             "rank0_mip_gather_s": round(gather_s[0], 4),
@@ -206,7 +216,8 @@ def main():
             "rank0_cost_evaluations_per_time_point": round(float(np.mean(evals)), 1) if evals else 0,
             "mip_stack": list(stack.shape), "mip_checksum": float(stack.double().sum().item()),
         }))
-    pipe.close()
+    for p in pipes:
+        p.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
