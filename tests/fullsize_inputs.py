@@ -86,6 +86,22 @@ def psf_b():
     return binomial_psf(9, 9, 33)
 
 
+def psf_bench_like():
+    """64 x 64 x 64, even-sized and anisotropic like bench.py's Gaussian (sigma (z, y, x) ~ (6, 2.5, 2.5)): rows of a
+    binomial of width 4 sigma^2 + 1 centred at index 32 and zero-padded to 64 samples, scaled by exact powers of two --
+    additions and multiplications of float64 numbers only, cast to float32 at the end."""
+    def row(n_taps):
+        r = np.ones(1, dtype=np.float64)
+        for _ in range(n_taps - 1):
+            r = np.convolve(r, np.array([0.5, 0.5]))
+        out = np.zeros(64, dtype=np.float64)
+        lo = 32 - n_taps // 2
+        out[lo:lo + n_taps] = r
+        return out
+    p = row(63)[:, None, None] * row(25)[None, :, None] * row(25)[None, None, :]  # sigma = sqrt(n - 1) / 2 = 3.9, 2.4, 2.4
+    return (p * 2.0 ** 20).astype(np.float32)
+
+
 def sample_indices(n_voxels, count=N_SAMPLES):
     return (np.arange(count, dtype=np.int64) * SAMPLE_STRIDE + 7) % n_voxels
 

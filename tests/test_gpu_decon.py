@@ -324,6 +324,34 @@ def test_full_size_vs_oracle_fixture(dev, backend):
     eng.close()
 
 
+def test_full_size_bench_like_psf_vs_oracle_fixture(dev, api):
+    """The same at the PSF extent bench.py times: 64 x 64 x 64, even-sized, anisotropic (tests/fullsize_inputs.py
+    psf_bench_like) -- the fused backend's two-pass kernels, the rocFFT backend and decon_singleview through host pointers
+    against 20 oracle iterations (tests/golden/make_golden_fullsize.py psf64)."""
+    import torch
+    from tests import fullsize_inputs as fi
+    path = os.path.join(GOLD, "fullsize_decon_psf64.npz")
+    if not os.path.exists(path):
+        pytest.skip("fullsize_decon_psf64.npz not generated")
+    g = np.load(path)
+    shape = fi.FULL_SHAPE
+    img, psf = fi.hash_volume(shape, 1), fi.psf_bench_like()
+    assert float(psf.sum(dtype=np.float64)) == float(g["psf_sum"])  # the PSF is the fixture's PSF
+    for backend in (2, 1):
+        eng = dev.DeconEngine(shape, backend=backend)
+        A = T(img)
+        E = torch.empty_like(A)
+        otf, bp = eng.gen_otf(T(psf)), eng.gen_otf(T(psf), flip=True)
+        eng.init_single(A, E)
+        eng.run_single(E, A, otf, bp, int(g["iters"]))
+        eng.sync()
+        _check_fullsize(E, g, "sv")
+        eng.close()
+        del A, E, otf, bp
+    out, _ = api.decon_singleview(img, psf, int(g["iters"]))
+    _check_fullsize(out, g, "sv")
+
+
 def test_full_size_libapi_vs_oracle_fixture(api):
     """The same fixture through the reference's host-pointer entry points (include/libapi.h:42-46)."""
     from tests import fullsize_inputs as fi

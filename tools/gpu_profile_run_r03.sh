@@ -16,7 +16,7 @@ find $out -size +20M -delete
 cat $out/tests.log $out/bench.json
 timeout 900 python tools/bench_sizes.py > $out/bench_sizes.log 2>&1; cp gpurun_out/bench_sizes.json $out/bench_sizes.json
 # BASELINE.json configs[4] on one GPU
-( timeout 300 python tools/bench_batch.py --time-points 8; timeout 300 python tools/bench_batch.py --time-points 8 --overlap; timeout 300 python tools/bench_batch.py --time-points 8 --lanes 2; timeout 300 python tools/bench_batch.py --time-points 12 --lanes 3; timeout 300 python tools/bench_batch.py --time-points 8 --reg-mode 2; timeout 300 python tools/bench_batch.py --time-points 8 --reg-mode 1; timeout 400 python tools/bench_batch.py --time-points 8 --tiff --overlap ) > $out/bench_batch.json 2> $out/bench_batch.err
+( timeout 300 python tools/bench_batch.py --time-points 8; timeout 300 python tools/bench_batch.py --time-points 8 --overlap; timeout 300 python tools/bench_batch.py --time-points 8 --lanes 2; timeout 300 python tools/bench_batch.py --time-points 12 --lanes 3; timeout 300 python tools/bench_batch.py --time-points 8 --reg-mode 2; timeout 300 python tools/bench_batch.py --time-points 8 --reg-mode 1; timeout 400 python tools/bench_batch.py --time-points 8 --tiff /tmp/mil_batch_tiff --overlap ) > $out/bench_batch.json 2> $out/bench_batch.err
 # the command-line tool end to end on TIFF files: reference main / our main / our main with worker threads, same library
 ( timeout 900 python tools/bench_cli_batch.py --time-points 16 --reg-mode 3 --workers 0,0 --distinct 4; timeout 900 python tools/bench_cli_batch.py --time-points 16 --reg-mode 2 --workers 0,0 --distinct 4 ) > $out/bench_cli_batch.json 2> $out/bench_cli_batch.err
 # registration cost kernel (tools/reg_profile_summary.py condenses these)
