@@ -362,8 +362,12 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
     }
     const bool fast = __all(whole) != 0;  // wave-uniform
 
+    // One voxel of one z step between `prepare` and `accumulate`.  Only the upper weight of each axis is carried; 1 - w is
+    // formed where it is used: 90 -> 82 registers.  (Compiled for SIX waves per SIMD -- 80 registers, nothing of the z loops
+    // spilled -- the kernels are SLOWER: 0.152 / 0.188-0.200 against 0.146 / 0.175 ms, profiles/r03/
+    // reg_cost_variants_six_waves_slim.txt; the five waves the compiler picks stay.)
     struct Vox {
-        f32x2 wx, wy, wz;  // (1 - w, w)
+        float wx1, wy1, wz1;
         unsigned off;
         bool in;
         float tv;
@@ -389,12 +393,8 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
             const f32x2 BX = TX - half2, BY = TY - half2, BZ = TZ - half2;
             const float fxA = floorf(BX.x), fyA = floorf(BY.x), fzA = floorf(BZ.x);
             const float fxB = floorf(BX.y), fyB = floorf(BY.y), fzB = floorf(BZ.y);
-            A.wx.y = BX.x - fxA; A.wx.x = 1.0f - A.wx.y;
-            A.wy.y = BY.x - fyA; A.wy.x = 1.0f - A.wy.y;
-            A.wz.y = BZ.x - fzA; A.wz.x = 1.0f - A.wz.y;
-            B.wx.y = BX.y - fxB; B.wx.x = 1.0f - B.wx.y;
-            B.wy.y = BY.y - fyB; B.wy.x = 1.0f - B.wy.y;
-            B.wz.y = BZ.y - fzB; B.wz.x = 1.0f - B.wz.y;
+            A.wx1 = BX.x - fxA; A.wy1 = BY.x - fyA; A.wz1 = BZ.x - fzA;
+            B.wx1 = BX.y - fxB; B.wy1 = BY.y - fyB; B.wz1 = BZ.y - fzB;
             constexpr int SH = PAIRS ? 3 : 2;
             {
                 // Index arithmetic without float -> int conversions: f + 1.5 * 2^23 is exact for the integer f (|f| < 2^22)
@@ -428,11 +428,12 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
         if constexpr (!PAIRS) {
             // plain layout: 8-byte gathers of (x0, x1) at rows y0, y1 of the lower and the upper plane
             auto accumulate = [&](const Vox &p, f32x2 lo0, f32x2 lo1, f32x2 up0, f32x2 up1, double &ss, double &st) {
-                const f32x2 p00 = p.wx * lo0, p01 = p.wx * lo1, p10 = p.wx * up0, p11 = p.wx * up1;
+                const f32x2 wx = {1.0f - p.wx1, p.wx1}, wy = {1.0f - p.wy1, p.wy1}, wz = {1.0f - p.wz1, p.wz1};
+                const f32x2 p00 = wx * lo0, p01 = wx * lo1, p10 = wx * up0, p11 = wx * up1;
                 const f32x2 lower = {p00.x + p00.y, p01.x + p01.y}, upper = {p10.x + p10.y, p11.x + p11.y};
-                const f32x2 el = p.wy * lower, eu = p.wy * upper;
+                const f32x2 el = wy * lower, eu = wy * upper;
                 const f32x2 e = {el.x + el.y, eu.x + eu.y};
-                const f32x2 rz = p.wz * e;
+                const f32x2 rz = wz * e;
                 finish(p, rz.x + rz.y, ss, st);
             };
             struct Taps { f32x2 r0, r1; };  // rows y0, y1 of one source plane, (x0, x1) each
@@ -492,12 +493,14 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
         } else {
             // row-pair layout: one 16-byte gather = (y0 x0, y1 x0, y0 x1, y1 x1) of a plane
             auto accumulate = [&](const Vox &p, f32x4 lo, f32x4 up, double &ss, double &st) {
+                const float wx0 = 1.0f - p.wx1;
+                const f32x2 wy = {1.0f - p.wy1, p.wy1}, wz = {1.0f - p.wz1, p.wz1};
                 const f32x2 lo_a = {lo.x, lo.y}, lo_b = {lo.z, lo.w}, up_a = {up.x, up.y}, up_b = {up.z, up.w};
-                const f32x2 cl = lo_a * p.wx.x + lo_b * p.wx.y;
-                const f32x2 cu = up_a * p.wx.x + up_b * p.wx.y;
-                const f32x2 el = p.wy * cl, eu = p.wy * cu;
+                const f32x2 cl = lo_a * wx0 + lo_b * p.wx1;
+                const f32x2 cu = up_a * wx0 + up_b * p.wx1;
+                const f32x2 el = wy * cl, eu = wy * cu;
                 const f32x2 e = {el.x + el.y, eu.x + eu.y};
-                const f32x2 rz = p.wz * e;
+                const f32x2 rz = wz * e;
                 finish(p, rz.x + rz.y, ss, st);
             };
             Vox cA, cB;
