@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapi.so")
+# MIL_LIBAPI_PATH: load another build of the library (A/B timing of experimental builds; tools/ only)
+LIB_PATH = os.environ.get("MIL_LIBAPI_PATH") or os.path.join(_HERE, "libapi.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_uint_p = C.POINTER(C.c_uint)

@@ -29,7 +29,8 @@ namespace {
 
 constexpr int kTileX = 64;  // one wave = 64 consecutive x: coalesced target reads
 constexpr int kTileY = 4;   // waves per workgroup
-constexpr int kStepsZ = 16; // z steps per lane
+constexpr int kStepsZ = 16; // z steps per lane (8: 0.198 / 0.201 ms at the identity / 3 deg + 2 %, 32: 0.145 / 0.179, 16: 0.146 / 0.177 --
+                            // profiles/r03/reg_cost_variants_z_steps.txt)
 constexpr int kThreads = kTileX * kTileY;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
