@@ -121,7 +121,9 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
                          const float *m12, double *h_out, void *stream);
 /* test / profiling aid (process-wide): pin the padded-source kernel -- 0 plain layout + plane reuse, 1 row-pair layout,
  * 2 row-pair layout + plane reuse, 3 / 4 / 5 the same with two voxels per lane (target widths that are multiples of 128;
- * otherwise the one-voxel form runs); -1 (default) chooses per matrix.  Every choice returns the same sums. */
+ * otherwise the one-voxel form runs), 6 plain layout, two voxels per lane, marching along y with row reuse; -1 (default)
+ * chooses per matrix.  Kernels 0-5 return the same bits; kernel 6 sums the same voxel values in another order (equal to
+ * ~1e-15 relative). */
 int mil_corr_padded_force_kernel(int kernel);
 /* host logic only (no GPU needed): which of the three the per-matrix choice takes for m12 */
 int mil_corr_padded_pick_kernel(const float *m12);

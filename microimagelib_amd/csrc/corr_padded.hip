@@ -322,7 +322,17 @@ __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__r
 // Each voxel keeps its own float64 accumulators, and the sums are combined in the order the one-voxel-per-lane kernels
 // use -- a wave here covers two of their waves, a workgroup two of their workgroups, published separately
 // (corr_publish_as) -- so every cost kernel returns the same bits.
-template <bool PAIRS, bool REUSE>
+//
+// MARCHY (plain layout with reuse only): the lane marches along y inside ONE target plane instead of along z -- tiles of
+// 128 (x) x 16 (y steps) x 4 (z: the waves) -- and reuses source ROWS instead of planes.  Which axis to march along decides
+// how often a wave needs its wave-wide re-gather: per step the two coordinates ACROSS the marching axis drift by
+// (m2, m6) along z but by (m1, m9) along y, and the coordinate ALONG it skips an index when its scale differs from 1 -- for
+// the lanes of a wave together if that coordinate does not depend on x.  A rotation about y with a 2 % scale (bench.py's
+// matrix) re-gathers in 83 % of the wave-steps along z and in 2 % along y: 0.202 -> 0.161 ms per evaluation, past the
+// row-pair kernels' 0.175 on 2/3 of their HBM traffic (profiles/r03/reg_cost_variants_march_y.txt).  The host picks the
+// axis per matrix (pick_kernel).  Same voxels, same float32 values; the float64 partial sums are formed in another order
+// (16 y steps per lane), so the two sums agree with the other kernels' to ~1e-15 relative, not bit for bit.
+template <bool PAIRS, bool REUSE, bool MARCHY = false>
 __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, const float *__restrict__ srcp,
                                                const PaddedArgs &a, const CorrTail &tail, int old_grid_x, double *lds,
                                                int *last_p) {
@@ -331,24 +341,35 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
     corr_tile_of_block(a.gx, a.gy, bx, by, bz);
     const int x = bx * 2 * kTileX + lane;  // voxel A; voxel B sits kTileX further on (the next 64-wide workgroup of the
                                            // one-voxel-per-lane decomposition); tx % 128 == 0 (host check)
-    const int y = by * kTileY + wave;
+    static_assert(!MARCHY || (!PAIRS && REUSE), "the y-marching form exists for the plain layout with reuse");
+    // `fixed` = the coordinate of this wave across the marching axis (y, or z when marching along y); [z0, z1) = the steps
+    const int fixed = by * kTileY + wave;
     const int z0 = bz * kStepsZ;
-    const int z1 = (z0 + kStepsZ < a.tz) ? z0 + kStepsZ : a.tz;
+    const int n_steps = MARCHY ? a.ty : a.tz;
+    const int z1 = (z0 + kStepsZ < n_steps) ? z0 + kStepsZ : n_steps;
     double ssA = 0.0, stA = 0.0, ssB = 0.0, stB = 0.0;
-    const bool active = x < a.tx && y < a.ty;
-    const float iy = (float)y;
+    const bool active = x < a.tx && fixed < (MARCHY ? a.tz : a.ty);
+    const float ifix = (float)fixed;
     const f32x2 ixs = {(float)x, (float)(x + kTileX)};
     const f32x2 half2 = {0.5f, 0.5f};
-    // per-axis constant part m0*x + m1*y of both voxels, (voxel A, voxel B)
-    const f32x2 HX = ixs * a.m[0] + (f32x2){a.m[1] * iy, a.m[1] * iy};
-    const f32x2 HY = ixs * a.m[4] + (f32x2){a.m[5] * iy, a.m[5] * iy};
-    const f32x2 HZ = ixs * a.m[8] + (f32x2){a.m[9] * iy, a.m[9] * iy};
-    auto coords = [&](int z, f32x2 &TX, f32x2 &TY, f32x2 &TZ) {
-        const float iz = (float)z;
-        const float zx = a.m[2] * iz, zy = a.m[6] * iz, zz = a.m[10] * iz;
-        TX = ((HX + (f32x2){zx, zx}) + (f32x2){a.m[3], a.m[3]}) + half2;
-        TY = ((HY + (f32x2){zy, zy}) + (f32x2){a.m[7], a.m[7]}) + half2;
-        TZ = ((HZ + (f32x2){zz, zz}) + (f32x2){a.m[11], a.m[11]}) + half2;
+    // t = ((m0*x + m1*y) + m2*z) + m3, then + 0.5: the reference's left-to-right float32 evaluation for both voxels
+    // (voxel A, voxel B).  Marching along z the first sum is constant; marching along y the z product is.
+    const f32x2 PX = ixs * a.m[0], PY = ixs * a.m[4], PZ = ixs * a.m[8];
+    const float cx = (MARCHY ? a.m[2] : a.m[1]) * ifix, cy = (MARCHY ? a.m[6] : a.m[5]) * ifix, cz = (MARCHY ? a.m[10] : a.m[9]) * ifix;
+    const f32x2 HX = PX + (f32x2){cx, cx}, HY = PY + (f32x2){cy, cy}, HZ = PZ + (f32x2){cz, cz};  // z-marching form only
+    auto coords = [&](int step, f32x2 &TX, f32x2 &TY, f32x2 &TZ) {
+        const float is = (float)step;
+        if constexpr (MARCHY) {
+            const float yx = a.m[1] * is, yy = a.m[5] * is, yz = a.m[9] * is;
+            TX = (((PX + (f32x2){yx, yx}) + (f32x2){cx, cx}) + (f32x2){a.m[3], a.m[3]}) + half2;
+            TY = (((PY + (f32x2){yy, yy}) + (f32x2){cy, cy}) + (f32x2){a.m[7], a.m[7]}) + half2;
+            TZ = (((PZ + (f32x2){yz, yz}) + (f32x2){cz, cz}) + (f32x2){a.m[11], a.m[11]}) + half2;
+        } else {
+            const float zx = a.m[2] * is, zy = a.m[6] * is, zz = a.m[10] * is;
+            TX = ((HX + (f32x2){zx, zx}) + (f32x2){a.m[3], a.m[3]}) + half2;
+            TY = ((HY + (f32x2){zy, zy}) + (f32x2){a.m[7], a.m[7]}) + half2;
+            TZ = ((HZ + (f32x2){zz, zz}) + (f32x2){a.m[11], a.m[11]}) + half2;
+        }
     };
     auto inside = [&](float tx_, float ty_, float tz_) {
         return tx_ > 0 && tx_ < a.sxf && ty_ > 0 && ty_ < a.syf && tz_ > 0 && tz_ < a.szf;
@@ -377,11 +398,15 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(srcp), 0, (int)a.bytes, 0x00020000);
     const unsigned sRow = (unsigned)a.row4, sPlane = (unsigned)a.plane4, sBoth = (unsigned)(a.plane4 + a.row4);
     const char *tbase = reinterpret_cast<const char *>(tgt);
-    const unsigned tstep = 4u * (unsigned)a.tx * (unsigned)a.ty;
+    const unsigned tstep = MARCHY ? 4u * (unsigned)a.tx : 4u * (unsigned)a.tx * (unsigned)a.ty;
+    // the source step the reuse expects (one row / one plane further) and the offsets of the four (x0, x1) gathers of a
+    // voxel: (plane z0, plane z1) of one row when marching along y, (row y0, row y1) of one plane when marching along z
+    const unsigned sStep = MARCHY ? sRow : sPlane, sSide = MARCHY ? sPlane : sRow;
 
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
-        unsigned toff = 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)y + (unsigned)a.ty * (unsigned)z0));
+        unsigned toff = MARCHY ? 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)z0 + (unsigned)a.ty * (unsigned)fixed))
+                               : 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)fixed + (unsigned)a.ty * (unsigned)z0));
         auto prepare = [&](int z, unsigned toff, Vox &A, Vox &B) {
             f32x2 TX, TY, TZ;
             coords(z, TX, TY, TZ);
@@ -437,9 +462,14 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
                 const f32x2 rz = wz * e;
                 finish(p, rz.x + rz.y, ss, st);
             };
-            struct Taps { f32x2 r0, r1; };  // rows y0, y1 of one source plane, (x0, x1) each
+            struct Taps { f32x2 r0, r1; };  // the two (x0, x1) pairs of one step: rows y0, y1 of a plane / planes z0, z1 of a row
             auto plane = [&](unsigned off, bool upper) {
-                return Taps{gather_pair(rsrc, off, upper ? sPlane : 0u), gather_pair(rsrc, off, upper ? sBoth : sRow)};
+                return Taps{gather_pair(rsrc, off, upper ? sStep : 0u), gather_pair(rsrc, off, upper ? sBoth : sSide)};
+            };
+            // the interpolation takes (z0 y0, z0 y1, z1 y0, z1 y1)
+            auto interp = [&](const Vox &p, const Taps &lo, const Taps &up, double &ss, double &st) {
+                if constexpr (MARCHY) accumulate(p, lo.r0, up.r0, lo.r1, up.r1, ss, st);
+                else accumulate(p, lo.r0, lo.r1, up.r0, up.r1, ss, st);
             };
             Vox cA, cB;
             prepare(z0, toff, cA, cB);
@@ -453,8 +483,8 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
                 Vox nA, nB;
                 prepare(z, toff, nA, nB);
                 if (CHECK && REUSE) {  // out of the window: ride on the offset the plane reuse expects
-                    nA.off = nA.in ? nA.off : cA.off + sPlane;
-                    nB.off = nB.in ? nB.off : cB.off + sPlane;
+                    nA.off = nA.in ? nA.off : cA.off + sStep;
+                    nB.off = nB.in ? nB.off : cB.off + sStep;
                 }
                 aNx = plane(nA.off, true);
                 bNx = plane(nB.off, true);
@@ -463,15 +493,15 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
                     al = plane(nA.off, false);
                     bl = plane(nB.off, false);
                 }
-                accumulate(cA, aLo.r0, aLo.r1, aUp.r0, aUp.r1, ssA, stA);
-                accumulate(cB, bLo.r0, bLo.r1, bUp.r0, bUp.r1, ssB, stB);
+                interp(cA, aLo, aUp, ssA, stA);
+                interp(cB, bLo, bUp, ssB, stB);
                 if (REUSE) {
                     // keep the (rare) re-gather BELOW the interpolation that still reads the upper plane (the empty asm
                     // pins the four sums here): issued above it, the load needs a copy of the register set -- 4 moves
                     // per voxel, measured in the ISA
                     asm volatile("" : "+v"(ssA), "+v"(stA), "+v"(ssB), "+v"(stB) : : "memory");
-                    if (nA.off != cA.off + sPlane) aUp = plane(nA.off, false);
-                    if (nB.off != cB.off + sPlane) bUp = plane(nB.off, false);
+                    if (nA.off != cA.off + sStep) aUp = plane(nA.off, false);
+                    if (nB.off != cB.off + sStep) bUp = plane(nB.off, false);
                 } else {
                     aUp = al;
                     bUp = bl;
@@ -489,8 +519,8 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
                 step(z, aP, aQ, aR, bP, bQ, bR);
                 aP = aQ; aQ = aR; bP = bQ; bQ = bR;
             }
-            accumulate(cA, aP.r0, aP.r1, aQ.r0, aQ.r1, ssA, stA);
-            accumulate(cB, bP.r0, bP.r1, bQ.r0, bQ.r1, ssB, stB);
+            interp(cA, aP, aQ, ssA, stA);
+            interp(cB, bP, bQ, ssB, stB);
         } else {
             // row-pair layout: one 16-byte gather = (y0 x0, y1 x0, y0 x1, y1 x1) of a plane
             auto accumulate = [&](const Vox &p, f32x4 lo, f32x4 up, double &ss, double &st) {
@@ -585,13 +615,13 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
     }
 }
 
-template <bool PAIRS, bool REUSE>
+template <bool PAIRS, bool REUSE, bool MARCHY = false>
 __global__ __launch_bounds__(kThreads) void corr_pair_kernel(const float *__restrict__ tgt,
                                                            const float *__restrict__ srcp, PaddedArgs a,
                                                            CorrTail tail, int old_grid_x) {
     __shared__ double lds[4 * kTileY];
     __shared__ int last;
-    corr_pair_body<PAIRS, REUSE>(tgt, srcp, a, tail, old_grid_x, lds, &last);
+    corr_pair_body<PAIRS, REUSE, MARCHY>(tgt, srcp, a, tail, old_grid_x, lds, &last);
 }
 
 // dst[z+1][y+1][x+1] = (src[z][y][x], src[z][y+1][x]) with edge replication; y runs over [-1, sy-1].
@@ -668,28 +698,46 @@ namespace {
 //   < 0.08  plain layout + plane reuse           (translations, pure scales, rotations up to ~2 degrees)
 //   < 0.6   row pairs + plane reuse              (the usual registration matrix: a few degrees AND a few per cent)
 //   else    row pairs, both planes gathered      (large rotations)
-std::atomic<int> g_forced_kernel{-1};  // test / profiling aid (process-wide), corr_padded_force_kernel(): 0-2 one voxel per lane, 3-5 two
+std::atomic<int> g_forced_kernel{-1};  // test / profiling aid (process-wide), corr_padded_force_kernel(): 0-2 one voxel per lane, 3-5 two, 6 two + marching along y
+
+// Expected number of wave-wide re-gathers per step when a wave of 64 consecutive x marches along z / along y (see the
+// comment above): the drift of the two coordinates across the marching axis, and the index skips of the one along it,
+// each times the number of distinct sub-voxel phases the wave's lanes carry for that coordinate.
+void exception_rates(const float *m, double &along_z, double &along_y) {
+    auto frac_dist = [](double v) { return std::fabs(v - std::nearbyint(v)); };
+    auto phases = [&](double per_x) { return std::min(64.0, 1.0 + 64.0 * frac_dist(per_x)); };
+    const double px = phases(m[0]), py = phases(m[4]), pz = phases(m[8]);
+    along_z = std::fabs((double)m[2]) * px + std::fabs((double)m[6]) * py + std::fabs((double)m[10] - 1.0) * pz;
+    along_y = std::fabs((double)m[1]) * px + std::fabs((double)m[5] - 1.0) * py + std::fabs((double)m[9]) * pz;
+}
 
 int pick_layout(const float *m, bool has_pairs) {
     if (!has_pairs) return 0;
-    auto frac_dist = [](double v) { return std::fabs(v - std::nearbyint(v)); };
-    auto phases = [&](double per_x) { return std::min(64.0, 1.0 + 64.0 * frac_dist(per_x)); };
-    const double rate = std::fabs((double)m[2]) * phases(m[0]) + std::fabs((double)m[6]) * phases(m[4]) +
-                        std::fabs((double)m[10] - 1.0) * phases(m[8]);
+    double rate, rate_y;
+    exception_rates(m, rate, rate_y);
     if (!(rate >= 0.08)) return 0;  // also NaN
     return rate < 0.6 ? 2 : 1;
 }
 
 // 0 plain + reuse | 1 row pairs | 2 row pairs + reuse: one voxel per lane; 3 / 4 / 5: the same with two voxels per lane
-// (needs a target width that is a multiple of 128).  Measured at 512 x 512 x 256 (tools/bench_corr.py, ms per evaluation):
+// (needs a target width that is a multiple of 128); 6: plain + reuse, two voxels per lane, MARCHING ALONG Y.
+// Measured at 512 x 512 x 256 (tools/bench_corr.py, ms per evaluation):
 // the two-voxel form wins wherever the plane reuse mostly holds (identity 0.156 vs 0.171, 2 % scale 0.152 vs 0.157,
 // 3 deg + 2 % 0.191 vs 0.199); with both planes gathered every step (large rotations) the one-voxel form keeps fewer
-// cache lines per gather in flight and wins (45 deg: 0.500 vs 0.541).
+// cache lines per gather in flight and wins (45 deg: 0.500 vs 0.541).  Round 3: where the reuse would hold along y but not
+// along z (rotations about y, as in bench.py: 83 % against 2 % of the wave-steps re-gather), kernel 6 runs the plain layout at
+// 0.161 ms where the row pairs take 0.175 and the plain z-marching form 0.202.
 int pick_kernel(const float *m, bool has_pairs, bool wide) {
     const int forced = g_forced_kernel;
+    if (forced == 6) return wide ? 6 : 0;
     if (forced >= 0 && forced <= 5) {
         const int layout = forced % 3;
         return ((layout == 0 || has_pairs) ? layout : 0) + ((forced >= 3 && wide) ? 3 : 0);
+    }
+    if (wide) {
+        double rz, ry;
+        exception_rates(m, rz, ry);
+        if (ry < 0.08 && ry < 0.5 * rz) return 6;  // a clear win only: at equal rates the z-marching forms stay
     }
     const int layout = pick_layout(m, has_pairs);
     return layout + ((wide && layout != 1) ? 3 : 0);
@@ -709,6 +757,7 @@ int magic_origin(int origin4, int row4, int plane4, int shift) {
 void corr_padded_force_kernel(int kernel) { g_forced_kernel = kernel; }
 
 int corr_padded_pick_kernel(const Affine12 &m) { return pick_layout(m.m, true); }
+int corr_padded_pick_kernel_wide(const Affine12 &m) { return pick_kernel(m.m, true, true); }
 
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
                             hipStream_t s) {
@@ -721,13 +770,18 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
     const long long xp = src.dims.nx + 2, yp = src.dims.ny + 2, yp2 = src.dims.ny + 1, zp = src.dims.nz + 2;
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kStepsZ - 1) / kStepsZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
-    // the partials are those of the 64 x 4 x 16 decomposition whichever kernel runs
-    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
     // two voxels per lane (x and x + 64): whole 128-wide workgroups only
     // ... and source extents the bit-pattern index arithmetic of corr_pair_kernel holds exactly (|index| < 2^22)
     const bool wide = a.tx % (2 * kTileX) == 0 && xp < (1 << 22) && yp < (1 << 22) && zp < (1 << 22);
     const int kernel = pick_kernel(a.m, src.has_pairs, wide);
-    const int layout = kernel % 3;
+    const int layout = kernel == 6 ? 0 : kernel % 3;
+    if (kernel == 6) {  // marching along y: tiles of 128 (x) x 16 (y) x 4 (z)
+        grid.y = (unsigned)((a.tz + kTileY - 1) / kTileY);
+        grid.z = (unsigned)((a.ty + kStepsZ - 1) / kStepsZ);
+        if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    }
+    // the partials are those of the 64 x 4 x 16 decomposition whichever z-marching kernel runs (64 x 16 x 4 for kernel 6)
+    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
     const int old_gx = (int)grid.x;
     if (kernel >= 3) grid.x = (grid.x + 1) / 2;  // 128 x per workgroup
     a.gx = (int)grid.x;
@@ -755,7 +809,9 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
         a.origin4 = (int)(4 * (pitch * yp + pitch + 1));
         a.bytes = (unsigned)(4 * pitch * yp * zp);
         a.origin4m = magic_origin(a.origin4, a.row4, a.plane4, 2);
-        if (kernel == 3)
+        if (kernel == 6)
+            hipLaunchKernelGGL((corr_pair_kernel<false, true, true>), grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail, old_gx);
+        else if (kernel == 3)
             hipLaunchKernelGGL((corr_pair_kernel<false, true>), grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail, old_gx);
         else
             hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail);

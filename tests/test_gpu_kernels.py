@@ -193,6 +193,18 @@ def _bits(v):
     return np.float64(v).view(np.uint64)
 
 
+def _same_sums(got, want, kern):
+    """Kernels 0-5 form their float64 partial sums in ONE order (the 64 x 4 x 16 decomposition): same bits.  Kernel 6 marches
+    along y (16 y steps per lane) and the per-matrix choice (-1) may pick it: same voxels and float32 values, another order of
+    the float64 additions -- equal to 1e-13 of the sum of squares."""
+    if kern in (0, 1, 2, 3, 4, 5):
+        return (np.float64(got[0]).view(np.uint64), np.float64(got[1]).view(np.uint64)) == \
+               (np.float64(want[0]).view(np.uint64), np.float64(want[1]).view(np.uint64))
+    tol = 1e-13 * max(abs(want[0]), 1e-300)
+    return abs(got[0] - want[0]) <= tol and abs(got[1] - want[1]) <= tol
+
+
+
 def test_padded_cost_kernel_is_bit_identical(dev):
     """The registration's cost kernels read the source through border-padded copies (csrc/corr_padded.hip: plain and
     row-pair layouts, with and without plane reuse): same two sums, bit for bit, as the general kernel -- golden matrices (texel centres, edges, all-out-of-window), random
@@ -202,10 +214,10 @@ def test_padded_cost_kernel_is_bit_identical(dev):
     pad = dev.PaddedSource(src)
     for i, m in enumerate(g["mats"]):
         a = dev.corr_sums(tgt, src, m)
-        for kern in (-1, 0, 1, 2, 3, 4, 5):  # per-matrix choice, then each padded-source kernel (3-5: two voxels per lane)
+        for kern in (-1, 0, 1, 2, 3, 4, 5, 6):  # per-matrix choice, then each padded-source kernel (3-6: two voxels per lane)
             dev.corr_padded_force_kernel(kern)
             b = dev.corr_sums(tgt, pad, m)
-            assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"golden matrix {i}, kernel {kern}"
+            assert _same_sums(b, a, kern), f"golden matrix {i}, kernel {kern}: {b} vs {a}"
         dev.corr_padded_force_kernel(-1)
         want_ss, want_st = g["corr_sums"][i]
         assert abs(b[0] - want_ss) <= 1e-12 * max(abs(want_ss), 1e-30)
@@ -242,10 +254,10 @@ def test_padded_cost_kernel_is_bit_identical(dev):
         mats.append(np.full(12, np.nan, dtype=f32))
         for i, m in enumerate(mats):
             a = dev.corr_sums(dt, ds, m)
-            for kern in (-1, 0, 1, 2, 3, 4, 5):
+            for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
                 dev.corr_padded_force_kernel(kern)
                 b = dev.corr_sums(dt, pad, m)
-                assert (_bits(a[0]), _bits(a[1])) == (_bits(b[0]), _bits(b[1])), f"{shape_s} matrix {i}, kernel {kern}"
+                assert _same_sums(b, a, kern), f"{shape_s} matrix {i}, kernel {kern}: {b} vs {a}"
             dev.corr_padded_force_kernel(-1)
             if i < 16:
                 wss, wst = ro.corr_sums(tgt, src, m)

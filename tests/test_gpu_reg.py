@@ -33,6 +33,18 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def _same_sums(got, want, kern):
+    """Kernels 0-5 form their float64 partial sums in ONE order (the 64 x 4 x 16 decomposition): same bits.  Kernel 6 marches
+    along y (16 y steps per lane) and the per-matrix choice (-1) may pick it: same voxels and float32 values, another order of
+    the float64 additions -- equal to 1e-13 of the sum of squares."""
+    if kern in (0, 1, 2, 3, 4, 5):
+        return (np.float64(got[0]).view(np.uint64), np.float64(got[1]).view(np.uint64)) == \
+               (np.float64(want[0]).view(np.uint64), np.float64(want[1]).view(np.uint64))
+    tol = 1e-13 * max(abs(want[0]), 1e-300)
+    return abs(got[0] - want[0]) <= tol and abs(got[1] - want[1]) <= tol
+
+
+
 def test_atrans3dgpu_golden(api):
     g = np.load(os.path.join(GOLD, "affine.npz"))
     for i, m in enumerate(g["mats"]):
@@ -282,9 +294,9 @@ def test_full_size_cost_and_resample_vs_oracle_fixture(dev, api):
         wss, wst = g["corr_sums"][i]
         ss, st = dev.corr_sums(t_dev, s_dev, m)
         assert abs(ss - wss) <= 1e-12 * wss and abs(st - wst) <= 1e-12 * wss, (i, ss, st, wss, wst)
-        for kern in (-1, 0, 1, 2, 3, 4, 5):
+        for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
             dev.corr_padded_force_kernel(kern)
-            assert dev.corr_sums(t_dev, pad, m) == (ss, st), f"matrix {i}, padded kernel {kern}"
+            assert _same_sums(dev.corr_sums(t_dev, pad, m), (ss, st), kern), f"matrix {i}, padded kernel {kern}"
     dev.corr_padded_force_kernel(-1)
     pad.close()
     del t_dev, s_dev
@@ -395,9 +407,9 @@ def test_full_size_registration_properties(dev):
     rot20[[3, 7]] = (90.0, -80.0)
     for m in (ident, rot, rot20):
         want = dev.corr_sums(ms, ms, m)
-        for kern in (-1, 0, 1, 2, 3, 4, 5):
+        for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
             dev.corr_padded_force_kernel(kern)
-            assert dev.corr_sums(ms, pad, m) == want, f"kernel {kern}"
+            assert _same_sums(dev.corr_sums(ms, pad, m), want, kern), f"kernel {kern}"
     dev.corr_padded_force_kernel(-1)
     # The last workgroup to finish sums the partials of all the others, which reach it through agent-scope stores and
     # loads instead of fences (csrc/corr_finish.h): hundreds of evaluations at full size must all publish the right bits.
@@ -497,7 +509,7 @@ def test_fenced_and_fence_free_tails_agree(dev, monkeypatch):
     c, s_ = np.cos(np.deg2rad(4.0)), np.sin(np.deg2rad(4.0))
     rot[[0, 2, 8, 10]] = np.array([c, -s_, s_, c], dtype=np.float32) * np.float32(0.98)
     rot[[3, 7, 11]] = (3.0, -2.0, 6.0)
-    for kern in (-1, 0, 1, 2, 3, 4, 5):
+    for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
         dev.corr_padded_force_kernel(kern)
         for m in (ident, rot):
             monkeypatch.delenv("MIL_CORR_FENCES", raising=False)
@@ -509,7 +521,8 @@ def test_fenced_and_fence_free_tails_agree(dev, monkeypatch):
     monkeypatch.setenv("MIL_CORR_FENCES", "1")
     a = dev.corr_sums(tgt, vol, rot)  # the general kernel (csrc/affine.hip) shares the tail
     monkeypatch.delenv("MIL_CORR_FENCES")
-    assert dev.corr_sums(tgt, vol, rot) == a == dev.corr_sums(tgt, pad, rot)
+    assert dev.corr_sums(tgt, vol, rot) == a
+    assert _same_sums(dev.corr_sums(tgt, pad, rot), a, -1)
     pad.close()
 
 
