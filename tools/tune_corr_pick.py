@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Which cost kernel is fastest for the matrices a registration really visits?  Times kernels 3 (plain, z), 6 (plain, y),
+5 (row pairs + reuse), 4 (row pairs, no reuse) and the library's own per-matrix choice on matrices sampled from the
+full-size trajectory fixture (tests/golden/fullsize_reg_traj_full.npz) and from bench.py's optimisation, 512 x 512 x 256.
+Evidence for the thresholds of pick_kernel (csrc/corr_padded.hip); not a test."""
+import os, sys, time, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from microimagelib_amd import device as mdev
+
+shape = (256, 512, 512)
+g = torch.Generator(device="cuda").manual_seed(0)
+tgt = torch.rand(shape, device="cuda", generator=g)
+src = torch.rand(shape, device="cuda", generator=g)
+pad = mdev.PaddedSource(src)
+
+
+def rates(m):
+    fd = lambda v: abs(v - round(v))
+    ph = lambda v: min(64.0, 1.0 + 64.0 * fd(v))
+    px, py, pz = ph(m[0]), ph(m[4]), ph(m[8])
+    rz = abs(m[2]) * px + abs(m[6]) * py + abs(m[10] - 1.0) * pz
+    ry = abs(m[1]) * px + abs(m[5] - 1.0) * py + abs(m[9]) * pz
+    return rz, ry
+
+
+mats = []
+tr = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_reg_traj_full.npz"))["trace"][:, :12]
+idx = np.linspace(0, len(tr) - 1, int(os.environ.get("TUNE_N", "160"))).astype(int)
+mats += [tr[i] for i in idx]
+# bench.py's optimum and single-parameter perturbations of it (what Powell's coordinate directions evaluate)
+c, s = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+lin = 1.02 * np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+centre = np.array([256.0, 256.0, 128.0])
+base = np.concatenate([lin, (centre - lin @ centre + np.array([5.0, -3.0, 2.0]))[:, None]], axis=1).astype(np.float32).reshape(12)
+mats.append(base)
+rng = np.random.default_rng(0)
+for k in range(12):
+    for d in (0.003, -0.01, 0.03):
+        m = base.copy()
+        m[k] += d * (50 if k in (3, 7, 11) else 1)
+        mats.append(m)
+n = 4
+rows = []
+for m in mats:
+    t = {}
+    for k in (-1, 3, 6, 5, 4):
+        mdev.corr_padded_force_kernel(k)
+        mdev.corr_sums(tgt, pad, m)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            mdev.corr_sums(tgt, pad, m)
+        t[k] = (time.perf_counter() - t0) / n * 1e3
+    rz, ry = rates([float(v) for v in m])
+    rows.append((rz, ry, t))
+mdev.corr_padded_force_kernel(-1)
+auto = np.mean([r[2][-1] for r in rows])
+best = np.mean([min(r[2][k] for k in (3, 6, 5, 4)) for r in rows])
+print(f"{len(rows)} matrices: per-matrix choice {auto:.4f} ms, best of (3, 6, 5, 4) per matrix {best:.4f} ms, "
+      f"always 3: {np.mean([r[2][3] for r in rows]):.4f}, always 6: {np.mean([r[2][6] for r in rows]):.4f}, "
+      f"always 5: {np.mean([r[2][5] for r in rows]):.4f}, always 4: {np.mean([r[2][4] for r in rows]):.4f}")
+print("  rz      ry     auto    k3     k6     k5     k4   best")
+for rz, ry, t in sorted(rows, key=lambda r: min(r[0], r[1])):
+    b = min((3, 6, 5, 4), key=lambda k: t[k])
+    print(f"{rz:6.3f} {ry:6.3f}  {t[-1]:.3f}  {t[3]:.3f}  {t[6]:.3f}  {t[5]:.3f}  {t[4]:.3f}   k{b}")
