@@ -19,9 +19,10 @@
 // starts its in-place transform with TWO radix-8 stages (fft_dev.h, pick_radix), so for any ny the "head" is 64 rows
 // y = n2 + T m (T = ny / 64) and the "tail" a transform of length T over T ADJACENT rows:
 //   xy_kernel<MODE, NY>      NY = 1024, 512, 256, 128 (T = 16, 8, 4, 2): 64 rows of one plane per thread; does not care about z
-//   yz_conv_kernel           ny = 512, nz = 256: register tiles
-//   yz_lds_kernel<NY, NZ>    the tile of T rows x 16 columns x all z FITS the LDS (T x nz <= 1024; ny = 1024, nz = 128: 8-column
-//                            tiles) and the same sequence runs on the classic LDS stage code
+//   yz_conv_kernel           ny = 512, nz = 256: register tiles of 8 rows x 8 columns x all z, two workgroups per CU
+//   yz_lds_kernel<NY, NZ>    the tile of T rows x 8 (16 for the smallest boxes) columns x all z FITS the LDS (T x nz <= 1024) and
+//                            the same sequence runs on the classic LDS stage code
+// The 8-column tiles are dealt so that the two halves of a 128-byte row segment land on the same XCD (yz_conv, host side).
 // => {256, 512, 1024} x {1024, 512, 256, 128} x {64, 128, 256} (x, y, z) without ... x 1024 x 256, and ... x 128 x 512:
 // 36 boxes.
 #include "fftconv.h"
@@ -166,8 +167,6 @@ struct YzArgs {
 #endif
 
 constexpr int kYzThreads = 512;
-constexpr int kXchg = 4 * 8 * 16 + 16;  // float2 between consecutive exchanged registers: 4 z-residues x 8 rows x 16 columns (+16: the
-                                         // register slots a wave reads at once fall on different bank halves)
 constexpr int kQuarter = 16;             // registers exchanged at a time (a quarter of the thread's 64)
 constexpr int kPark = 23;                // values of the waiting quarters parked in the rest of the 160 KB
 
@@ -181,28 +180,28 @@ __device__ __forceinline__ float2 swap_pair(float2 a) {
 // ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
 // One workgroup per pair of row blocks, 2 x T rows x NZ z of column 0 in LDS as tile[z][17].  `tw`: w_NZ^k, any address
 // space the 512 threads may index freely.
-template <int NY, int NZ, int NH>
+template <int NY, int NZ, int NH, int NT = 512>
 __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *tile, const float2 *tw, int pair) {
     constexpr int T = NY / 64, C = 2 * T;  // rows per block, columns of the tile in use
     constexpr int PW = C > kW ? C : kW, PWP = PW + 1;  // tile[z][PW + 1]
     constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
     const int tid = threadIdx.x;
     const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
-    for (int i = tid; i < NZ * C; i += kYzThreads) {
+    for (int i = tid; i < NZ * C; i += NT) {
         const int c = i % C, z = i / C;
         tile[z * PWP + c] = a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch];
     }
     if (C < PW)  // the z stages below run over all PW columns of the tile: keep the unused ones finite
-        for (int i = tid; i < NZ * (PW - C); i += kYzThreads) tile[(i / (PW - C)) * PWP + C + i % (PW - C)] = make_float2(0.f, 0.f);
+        for (int i = tid; i < NZ * (PW - C); i += NT) tile[(i / (PW - C)) * PWP + C + i % (PW - C)] = make_float2(0.f, 0.f);
     lds_barrier();
-    for (int i = tid; i < NZ * 2; i += kYzThreads) tail_forward<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
+    for (int i = tid; i < NZ * 2; i += NT) tail_forward<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
     lds_barrier();
-    fft_dif<NZ, NZ, -1, PW, kYzThreads, PWP>(tile, tw);
-    constexpr int PER = (NZ * C + kYzThreads - 1) / kYzThreads;
+    fft_dif<NZ, NZ, -1, PW, NT, PWP>(tile, tw);
+    constexpr int PER = (NZ * C + NT - 1) / NT;
     float2 r[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = i * kYzThreads + tid, c = e % C, p = e / C;
+        const int e = i * NT + tid, c = e % C, p = e / C;
         if (e < NZ * C) {
             const int row = T * blk[c / T] + (c % T);
             const int prow = a.neg_y[row];
@@ -216,45 +215,59 @@ __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *til
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = i * kYzThreads + tid;
+        const int e = i * NT + tid;
         if (e < NZ * C) tile[(e / C) * PWP + (e % C)] = r[i];
     }
     lds_barrier();
-    fft_dit<NZ, NZ, +1, PW, kYzThreads>(tile, tw);
-    for (int i = tid; i < NZ * 2; i += kYzThreads) tail_inverse<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
+    fft_dit<NZ, NZ, +1, PW, NT>(tile, tw);
+    for (int i = tid; i < NZ * 2; i += NT) tail_inverse<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
     lds_barrier();
     const int ncol = (blk[0] == blk[1]) ? T : C;
-    for (int i = tid; i < NZ * C; i += kYzThreads) {
+    for (int i = tid; i < NZ * C; i += NT) {
         const int c = i % C, z = i / C;
         if (c < ncol) a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch] = tile[z * PWP + c];
     }
 }
 
-template <int NH>
-__global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
+// COLS = 16: 512 threads, one workgroup per CU (the 256 KB tile).  COLS = 8: 256 threads and half the tile, TWO workgroups
+// per CU whose load / exchange / store phases overlap; the two halves of every 128-byte row segment go to workgroups t and
+// t + 8 -- the same XCD, a few dispatches apart -- so that HBM still sees whole lines (unpaired, the 64-byte segments cost
+// what the overlap gains: round 2).
+template <int NH, int COLS>
+__global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
+    static_assert(COLS == 16 || COLS == 8, "yz_conv_kernel: 16- or 8-column tiles");
+    constexpr int THREADS = 32 * COLS;           // COLS columns x 8 rows x 4 z-residues
+    constexpr int kXchg = 4 * 8 * COLS + COLS;   // float2 between consecutive exchanged registers: 4 z-residues x 8 rows x COLS
+                                                 // columns (+ COLS: the register slots a wave reads at once fall on different bank halves)
     constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
     constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8, kOtfBytes = (long long)NH * kNY * kNZ * 8;
     // exchange buffer of one quarter (66 KB) + parking space (92 KB): registers are the scarce resource of this kernel,
     // every spilled one is HBM traffic
-    __shared__ float2 lds[kQuarter * kXchg + kPark * kYzThreads];
+    __shared__ float2 lds[kQuarter * kXchg + kPark * THREADS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float2 *twz = c_tw_z;  // in-register stages; the packed-column path below uses the same table through LDS-style code
     if ((int)blockIdx.x >= a.pair_blocks) {
         const int tile_id = blockIdx.x - a.pair_blocks;
-        const int g = tile_id % kGroups, b = tile_id / kGroups;
+        int g = tile_id % (NH / COLS), b = tile_id / (NH / COLS);  // g: COLS-column group
+        if constexpr (COLS == 8) {  // XCD pairing of the two halves of a 16-column group (see yz_lds_kernel)
+            const int tt = tile_id % 16, q = tile_id / 16;
+            g = 2 * ((q % (NH / 128)) * 8 + (tt % 8)) + tt / 8;
+            b = q / (NH / 128);
+        }
+        const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // 16-column group of the OTF tiling, offset inside it
         // ownership 1: all z = za + 4m (m = j2 + 8 j1) of one (row j, column)
-        const int col = lane & 15, za = wave & 3, j = (lane >> 4) + 4 * (wave >> 2);
+        const int col = lane & (COLS - 1), za = wave & 3, j = (lane / COLS) + (64 / COLS) * (wave >> 2);
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes), ro = make_rsrc(a.otf, kOtfBytes);
         const unsigned voff = (unsigned)(j * kPitch + col) * 8u;
-        const unsigned soff0 = (unsigned)((za * kNY + 8 * b) * kPitch + g * kW) * 8u;  // + m * zstep
+        const unsigned soff0 = (unsigned)((za * kNY + 8 * b) * kPitch + g * COLS) * 8u;  // + m * zstep
         constexpr unsigned zstep = 4u * kNY * kPitch * 8u;
         // ownership 2 (per quarter q: ka = 2q, 2q + 1): a PAIR of lanes shares the 8 rows x 4 z-residues of one (register
         // slot kk = kb + 8 (ka - 2q), column); lane sp of the pair holds rows sp, sp + 2, sp + 4, sp + 6 going in and the
         // row frequencies 4 sp .. 4 sp + 3 at the OTF product (the radix-8 row butterfly split over the pair)
-        const int sp = tid & 1, scol = (tid >> 1) & 15, skk = tid >> 5;
-        const unsigned ooff0 = (unsigned)((((8 * b) * kGroups + g) * kNZ) * kW) * 8u;  // wave-uniform part (scalar offset)
-        const unsigned ovoff = (unsigned)((4 * sp * kGroups * kNZ + 4 * (skk & 7) + 32 * (skk >> 3)) * kW + scol) * 8u;  // row 4 sp, position 4 kb + 32 (ka - 2q)
+        const int sp = tid & 1, scol = (tid >> 1) & (COLS - 1), skk = tid / (2 * COLS);
+        const unsigned ooff0 = (unsigned)((((8 * b) * kGroups + g16) * kNZ) * kW) * 8u;  // wave-uniform part (scalar offset)
+        const unsigned ovoff = (unsigned)((4 * sp * kGroups * kNZ + 4 * (skk & 7) + 32 * (skk >> 3)) * kW + c16 + scol) * 8u;  // row 4 sp, position 4 kb + 32 (ka - 2q)
         float2 v[64], o[2][16];
         auto load_otf = [&](int q) {  // position kc + 4 kb + 32 ka of row frequency 4 sp + k
 #pragma unroll
@@ -292,28 +305,28 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
             for (int k = 0; k < 8; ++k) v[k + 8 * ka] = t[k];
         }
         MIL_STAMP(1);
-        float2 *mine = lds + za * 128 + j * 16 + col;                  // + kk * kXchg
-        float2 *slot = lds + skk * kXchg + sp * 16 + scol;              // + a * 128 + i * 32   (row sp + 2 i)
-        float2 *park = lds + kQuarter * kXchg + tid;                   // + i * kYzThreads, this thread's own slots
+        float2 *mine = lds + za * (8 * COLS) + j * COLS + col;         // + kk * kXchg
+        float2 *slot = lds + skk * kXchg + sp * COLS + scol;            // + a * 8 * COLS + i * 2 * COLS   (row sp + 2 i)
+        float2 *park = lds + kQuarter * kXchg + tid;                   // + i * THREADS, this thread's own slots
         // Parking plan (values by register index): v[32..54] wait in LDS from the start; when quarter 2 / 3 picks its inputs
         // up, the results of quarter 0 / 1 take the freed places; everything comes back after the last quarter.
 #pragma unroll
-        for (int i = 0; i < kPark; ++i) park[i * kYzThreads] = v[32 + i];
+        for (int i = 0; i < kPark; ++i) park[i * THREADS] = v[32 + i];
         constexpr float h8 = 0.70710678118654752440f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q == 2) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    v[32 + i] = park[i * kYzThreads];
-                    park[i * kYzThreads] = v[i];  // results of quarter 0
+                    v[32 + i] = park[i * THREADS];
+                    park[i * THREADS] = v[i];  // results of quarter 0
                 }
             }
             if (q == 3) {
 #pragma unroll
                 for (int i = 16; i < kPark; ++i) {
-                    v[32 + i] = park[i * kYzThreads];
-                    park[i * kYzThreads] = v[i];  // 7 results of quarter 1
+                    v[32 + i] = park[i * THREADS];
+                    park[i * THREADS] = v[i];  // 7 results of quarter 1
                 }
             }
 #pragma unroll
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
             if (q == 0) MIL_STAMP(9);
             float2 u[16];  // [a][i]: z-residue a, row sp + 2 i
 #pragma unroll
-            for (int e = 0; e < 16; ++e) u[e] = slot[(e >> 2) * 128 + (e & 3) * 32];
+            for (int e = 0; e < 16; ++e) u[e] = slot[(e >> 2) * (8 * COLS) + (e & 3) * (2 * COLS)];
             // y stage of length 8 over the rows, split over the lane pair (decimation in time): each lane transforms its four
             // rows, the odd lane applies w8^k, then  row k = even + odd,  row k + 4 = even - odd
 #pragma unroll
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
                 dft4<+1>(w[0], w[1], w[2], w[3]);
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) slot[(e >> 2) * 128 + (e & 3) * 32] = u[e];
+            for (int e = 0; e < 16; ++e) slot[(e >> 2) * (8 * COLS) + (e & 3) * (2 * COLS)] = u[e];
             if (q == 0) MIL_STAMP(12);
             lds_barrier();
             if (q == 0) MIL_STAMP(13);
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
             if (q < 2) MIL_STAMP(2 + q);
         }
 #pragma unroll
-        for (int i = 0; i < kPark; ++i) v[i] = park[i * kYzThreads];
+        for (int i = 0; i < kPark; ++i) v[i] = park[i * THREADS];
         // ---- z inverse, stages L = 32 and L = 256
 #pragma unroll
         for (int ka = 0; ka < 8; ++ka) {
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
 #endif
         return;
     }
-    packed_column_block<kNY, kNZ, NH>(a, lds, twz, (int)blockIdx.x);
+    packed_column_block<kNY, kNZ, NH, THREADS>(a, lds, twz, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(kYzThreads, 2) void yz_conv_kernel(YzArgs a) {
 // runs on tile[z][T rows x 16 columns] with the classic LDS stage code, T * 16 "columns" per z position.  One trip of the
 // spectrum through HBM (3 C'') where the classic kernels make three (y tail | z-conv | y tail^-1: 7 C'').
 // ---------------------------------------------------------------------------
-template <int NY, int NZ, int NH, int COLS>
+template <int NY, int NZ, int NH, int COLS, bool XCDPAIR = false>
 __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
     constexpr int T = NY / 64;
     // COLS columns per tile: 16 (128-byte row segments) wherever T x NZ x 16 complex fit the LDS, else 8 or 4
@@ -446,7 +459,18 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
     }
     constexpr int GROUPS = NH / COLS;
     const int tile_id = blockIdx.x - a.pair_blocks;
-    const int g = tile_id % GROUPS, b = tile_id / GROUPS;
+    int g = tile_id % GROUPS, b = tile_id / GROUPS;
+    if constexpr (XCDPAIR) {
+        // Narrow tiles (8 / 4 columns): the 2 / 4 pieces of a 128-byte row segment go to workgroups t, t + 8 (, t + 16,
+        // t + 24), i.e. to the SAME XCD (workgroups are dealt round-robin over the 8 XCDs) a few dispatches apart: the first
+        // one brings the line into that XCD's L2, the others find it there -- HBM sees whole lines again.
+        static_assert(!XCDPAIR || COLS < kW, "pairing is for narrow tiles");
+        constexpr int SUB = kW / COLS;
+        const int tt = tile_id % (8 * SUB), q = tile_id / (8 * SUB);
+        const int g16x = (q % (NH / 128)) * 8 + (tt % 8);  // 16-column group
+        g = SUB * g16x + tt / 8;
+        b = q / (NH / 128);
+    }
     const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // the 16-column group of the OTF tiling, offset inside it
     float2 *base = a.S + (long long)(T * b) * kPitch + g * COLS;
     constexpr long long zstride = (long long)NY * kPitch;
@@ -848,23 +872,28 @@ void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     auto grid_for = [&](int cols) { return dim3((unsigned)(64 * (xs_ / cols) + n_pairs_)); };  // 64 blocks of T rows, whatever ny is
     const float2 *twz = tw_z_.get();
     const int ny = (int)box_.ny, nz = (int)box_.nz;
-    // (8-column tiles -- 64-byte segments, two workgroups per CU at 512 x 512 x 128 -- measured: 2 200 against 2 170 it/s,
-    // within noise, profiles/r03/bench_box_nz128.txt; the 16-column form stays)
+    // Tiles are 8 columns wide wherever that leaves a workgroup enough work (T x nz >= 512): half the LDS per workgroup, so a CU
+    // holds two (or four) whose load / transform / store phases overlap, and the two halves of each 128-byte row segment go to
+    // workgroups t and t + 8 (same XCD, same L2) so HBM still moves whole lines.  Measured against unpaired 16-column tiles
+    // (profiles/r03/bench_box_paired8.txt): +5 % at 512 x 512 x 256 (register kernel), +9..13 % at T x nz = 1024, +3..5 % at 512;
+    // -1..+2 % below that, where 16 columns stay.  Unpaired 8-column tiles gain nothing (the 64-byte segments cost what the
+    // overlap wins: bench_box_narrow.txt).
     with_nh(box_.nx, [&](auto nh_tag) {
         constexpr int NH = decltype(nh_tag)::value;
-#define MIL_YZ(NY, NZ, COLS) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ, NH, COLS>), grid_for(COLS), block, 0, s, a, twz)
-        if (ny == kNY && nz == kNZ) hipLaunchKernelGGL(yz_conv_kernel<NH>, grid_for(kW), block, 0, s, a);
-        else if (ny == 1024 && nz == 128) MIL_YZ(1024, 128, 8);
-        else if (ny == 1024 && nz == 64) MIL_YZ(1024, 64, 16);
-        else if (ny == 512 && nz == 128) MIL_YZ(512, 128, 16);
-        else if (ny == 512 && nz == 64) MIL_YZ(512, 64, 16);
-        else if (ny == 256 && nz == 256) MIL_YZ(256, 256, 16);
-        else if (ny == 256 && nz == 128) MIL_YZ(256, 128, 16);
-        else if (ny == 256 && nz == 64) MIL_YZ(256, 64, 16);
-        else if (ny == 128 && nz == 512) MIL_YZ(128, 512, 16);
-        else if (ny == 128 && nz == 256) MIL_YZ(128, 256, 16);
-        else if (ny == 128 && nz == 128) MIL_YZ(128, 128, 16);
-        else if (ny == 128 && nz == 64) MIL_YZ(128, 64, 16);
+#define MIL_YZ(NY, NZ, COLS, PAIR) \
+    else if (ny == NY && nz == NZ) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ, NH, COLS, PAIR>), grid_for(COLS), block, 0, s, a, twz);
+        if (ny == kNY && nz == kNZ) hipLaunchKernelGGL((yz_conv_kernel<NH, 8>), grid_for(8), dim3(256), 0, s, a);
+        MIL_YZ(1024, 128, 8, true)
+        MIL_YZ(1024, 64, 8, true)
+        MIL_YZ(512, 128, 8, true)
+        MIL_YZ(512, 64, 8, true)
+        MIL_YZ(256, 256, 8, true)
+        MIL_YZ(256, 128, 8, true)
+        MIL_YZ(256, 64, 16, false)
+        MIL_YZ(128, 512, 8, true)
+        MIL_YZ(128, 256, 8, true)
+        MIL_YZ(128, 128, 16, false)
+        MIL_YZ(128, 64, 16, false)
         else throw Error(-1, "yz_conv: box outside the two-pass path");
 #undef MIL_YZ
     });
