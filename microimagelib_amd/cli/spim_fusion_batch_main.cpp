@@ -113,6 +113,11 @@ struct Log {
             ++next;
         }
     }
+    void flush() {  // after a failure: whatever was collected, in time-point order, gaps and all
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto &kv : waiting) emit(kv.second);
+        waiting.clear();
+    }
 };
 
 // text of one time point
@@ -309,19 +314,22 @@ int main(int argc, char **argv) {
     auto bad = [&](const RegState &st, const float *rec) {
         return !checkmatrix(const_cast<float *>(st.tmx), sx, sy, sz) || rec[3] < cost_bar;
     };
-    auto ladder = [&](RegState &st, Prepared &p, std::vector<float> &b_reg, float *rec, int choice_now, int dev, Lines &out) {
+    // Returns the status of the library call that failed (0: all calls succeeded).  A failed call leaves tmx / b_reg / rec
+    // untouched, so nothing below may use them: the caller stops the batch.
+    auto ladder = [&](RegState &st, Prepared &p, std::vector<float> &b_reg, float *rec, int choice_now, int dev, Lines &out) -> int {
         // first attempt, other scheme without the input matrix, then the input matrix itself
-        (void)run_reg(st, p, b_reg, rec, choice_now, st.have_itmx, dev);
+        if (int status = run_reg(st, p, b_reg, rec, choice_now, st.have_itmx, dev)) return status;
         if (bad(st, rec)) {
             out("\n\t... Attempt failed: transformation matrix problematic or cost function value %f < threshold %2.2f\n"
                 "\n\t... Change scheme and redo the registration!!!\n", rec[3], cost_bar);
-            (void)run_reg(st, p, b_reg, rec, choice_now == 4 ? 2 : 4, false, dev);
+            if (int status = run_reg(st, p, b_reg, rec, choice_now == 4 ? 2 : 4, false, dev)) return status;
             if (bad(st, rec) && st.have_itmx) {
                 out("\n\t... Attempt failed again: use input transformation matrix!!!\n");
                 std::memcpy(st.tmx, st.initial_tmx, sizeof st.tmx);
-                (void)run_reg(st, p, b_reg, rec, 0, true, dev);
+                if (int status = run_reg(st, p, b_reg, rec, 0, true, dev)) return status;
             }
         }
+        return 0;
     };
 
     // ---- regMode 1: register on the test image first (on the first device), then apply that matrix to every image
@@ -338,8 +346,9 @@ int main(int argc, char **argv) {
         if (!preprocess(p, device)) return 1;
         std::vector<float> b_reg(total);
         float rec[11] = {0};
-        ladder(base, p, b_reg, rec, reg_choice, device, out);
+        const int status = ladder(base, p, b_reg, rec, reg_choice, device, out);
         log.direct("%s", out.text.c_str());
+        if (status != 0) { printf("\t... registration of the test image failed (status %d), processing stopped !!!\n", status); return 1; }
         reg_mode = 0;
         base.have_itmx = true;
         std::memcpy(base.initial_tmx, base.tmx, sizeof base.tmx);
@@ -401,23 +410,24 @@ int main(int argc, char **argv) {
 
             // ---- registration (:714-843)
             RegState st = base;
+            int reg_status = 0;
             switch (reg_mode) {
-            case 0: (void)run_reg(st, p, b_reg, reg_records, 0, st.have_itmx, dev); break;
+            case 0: reg_status = run_reg(st, p, b_reg, reg_records, 0, st.have_itmx, dev); break;
             case 2: {
                 std::unique_lock<std::mutex> lock(chain.mu);
                 chain.cv.wait(lock, [&] { return chain.next >= (int)i; });
                 if (chain.next != (int)i) break;  // another worker failed
                 lock.unlock();  // the state is this worker's alone until it advances `next`
                 if (i == 0) {
-                    ladder(st, p, b_reg, reg_records, reg_choice, dev, out);
+                    reg_status = ladder(st, p, b_reg, reg_records, reg_choice, dev, out);
                     std::memcpy(chain.weighted, st.tmx, sizeof st.tmx);
                 } else {  // start from the running average, fall back to the previous matrix (:786-808)
                     std::memcpy(st.tmx, chain.weighted, sizeof st.tmx);
-                    (void)run_reg(st, p, b_reg, reg_records, 2, true, dev);
-                    if (bad(st, reg_records)) {
+                    reg_status = run_reg(st, p, b_reg, reg_records, 2, true, dev);
+                    if (reg_status == 0 && bad(st, reg_records)) {
                         out("\n\t... Attempt failed: use previous transformation matrix!!!\n");
                         std::memcpy(st.tmx, chain.previous, sizeof st.tmx);
-                        (void)run_reg(st, p, b_reg, reg_records, 0, true, dev);
+                        reg_status = run_reg(st, p, b_reg, reg_records, 0, true, dev);
                     }
                     for (int j = 0; j < 12; ++j) chain.weighted[j] = (float)(0.8 * chain.weighted[j] + 0.2 * st.tmx[j]);  // double arithmetic, :805-807
                 }
@@ -428,7 +438,13 @@ int main(int argc, char **argv) {
                 chain.cv.notify_all();
                 break;
             }
-            case 3: ladder(st, p, b_reg, reg_records, reg_choice, dev, out); break;
+            case 3: reg_status = ladder(st, p, b_reg, reg_records, reg_choice, dev, out); break;
+            }
+            if (reg_status != 0) {  // a library call failed (its message is on stderr): never write results made from stale buffers
+                out("\t... registration failed (status %d), processing stopped !!!\n", reg_status);
+                log.publish((int)i, std::move(out.text));
+                stop((int)i);
+                break;
             }
             if (failed) break;
             out("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
@@ -440,8 +456,14 @@ int main(int argc, char **argv) {
             const auto t2 = std::chrono::steady_clock::now();
 
             // ---- joint deconvolution (:874-911)
-            (void)decon_dualview(decon.data(), a.data.data(), b_reg.data(), size, psf1.data.data(), psf2.data.data(), psf1.size, false,
-                                 iters, dev, -1, true, decon_records, unmatch, bp1.data.data(), bp2.data.data());
+            if (const int status = decon_dualview(decon.data(), a.data.data(), b_reg.data(), size, psf1.data.data(), psf2.data.data(),
+                                                  psf1.size, false, iters, dev, -1, true, decon_records, unmatch, bp1.data.data(),
+                                                  bp2.data.data())) {
+                out("\t... deconvolution failed (status %d), processing stopped !!!\n", status);
+                log.publish((int)i, std::move(out.text));
+                stop((int)i);
+                break;
+            }
             out("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
                 decon_records[5]);
             if (behind.valid()) behind.get();  // the previous stack has left decon_out
@@ -492,7 +514,7 @@ int main(int argc, char **argv) {
         for (int w = 0; w < (int)devices.size(); ++w) threads.emplace_back(worker, w);
         for (auto &t : threads) t.join();
     }
-    if (failed) return 1;
+    if (failed) { log.flush(); return 1; }
     log.direct("\n=== Batch processing completed, whole time cost: %2.3f s\n", sec(t_batch, std::chrono::steady_clock::now()));
     return 0;
 }

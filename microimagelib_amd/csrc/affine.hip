@@ -279,15 +279,22 @@ CorrWorkspace::CorrWorkspace() {
     // coherent: the kernel's system-scope store of the ticket is visible to the polling host while the stream runs on
     MIL_HIP(hipHostMalloc((void **)&host, 3 * sizeof(double), hipHostMallocCoherent));
     host[0] = host[1] = host[2] = 0.0;
-    counter.alloc(kCorrCounters + 1);
-    MIL_HIP(hipMemset(counter.get(), 0, (kCorrCounters + 1) * sizeof(unsigned)));
+    counter.alloc(kCorrCounters + 1);  // zeroed by the first next(), ON THE STREAM the evaluation runs on
 }
 CorrWorkspace::~CorrWorkspace() {
     if (host) (void)hipHostFree(host);
 }
 
-CorrTail CorrWorkspace::next(size_t nblocks) {
+CorrTail CorrWorkspace::next(size_t nblocks, hipStream_t s) {
     if (nblocks == 0 || nblocks > (size_t)(1 << 30)) throw Error(-1, "corr_sums: volume exceeds launch limits");
+    if (!counters_zeroed) {
+        // hipMemset (no stream) is asynchronous to the host and runs on the NULL stream, which our non-blocking streams do not
+        // wait for: under load (several host threads on one device) it could land in the middle of the first evaluations and
+        // wipe the completion counts -- no workgroup was "last", nothing was published.  On the evaluation's own stream it is
+        // ordered before the first kernel.
+        MIL_HIP(hipMemsetAsync(counter.get(), 0, (kCorrCounters + 1) * sizeof(unsigned), s));
+        counters_zeroed = true;
+    }
     if (partials.size() < 2 * nblocks + 2 * kCorrCounters) partials.alloc(2 * nblocks + 2 * kCorrCounters);
     ticket += 1.0;
     const char *f = getenv("MIL_CORR_FENCES");  // read per evaluation: the tests flip it within one process
@@ -339,7 +346,7 @@ void corr_sums_async(const float *target, const float *src, Dims t_dims, Dims s_
     AffineArgs a = make_args(t_dims, s_dims, m);
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, (a.tz + kCorrZ - 1) / kCorrZ);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
-    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
+    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z, s);
     static const bool no_cache = getenv("MIL_CORR_NOCACHE") && getenv("MIL_CORR_NOCACHE")[0] == '1';
     if (float_products)  // 2-D images (one plane): nothing to reuse along z
         hipLaunchKernelGGL((corr_kernel<true, false>), grid, dim3(kBlockThreads), 0, s, target, src, a, tail);

@@ -781,7 +781,7 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
         if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
     }
     // the partials are those of the 64 x 4 x 16 decomposition whichever z-marching kernel runs (64 x 16 x 4 for kernel 6)
-    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z);
+    const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z, s);
     const int old_gx = (int)grid.x;
     if (kernel >= 3) grid.x = (grid.x + 1) / 2;  // 128 x per workgroup
     a.gx = (int)grid.x;

@@ -98,11 +98,12 @@ struct CorrWorkspace {
     DeviceBuffer<unsigned> counter;
     double *host = nullptr;  // pinned, coherent: {sum s*s, sum s*t, ticket of the evaluation they belong to}
     double ticket = 0.0;     // evaluations launched with this workspace
+    bool counters_zeroed = false;
     CorrWorkspace();
     ~CorrWorkspace();
     CorrWorkspace(const CorrWorkspace &) = delete;
     CorrWorkspace &operator=(const CorrWorkspace &) = delete;
-    CorrTail next(size_t nblocks);        // sizes the partials, takes a ticket
+    CorrTail next(size_t nblocks, hipStream_t s);  // sizes the partials, takes a ticket (first call: zeroes the counters on s)
     void wait(hipStream_t s);             // until the evaluation of the last ticket has published its sums
 };
 // Enqueue the fused interpolate + correlate + reduce (ONE launch); the result lands in ws.host, ws.wait() returns

@@ -6,7 +6,9 @@
 // one-worker files byte for byte; a per-device sleep shuffles the order in which workers finish.
 #include <unistd.h>
 
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -29,6 +31,11 @@ extern "C" bool checkmatrix(float *m, long long, long long, long long) { return 
 extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1, unsigned int *, int regChoice,
                      int, bool inputTmx, float, int, int deviceNum, int, bool, float *records) {
     jitter(deviceNum);
+    {   // MIL_STUB_FAIL_REG_CALL=k: the k-th registration call of the process fails like a library error (nothing written)
+        static std::atomic<int> calls{0};
+        const char *fail = getenv("MIL_STUB_FAIL_REG_CALL");
+        if (fail && ++calls == atoi(fail)) return -1;
+    }
     const size_t n = count3(imSize1);
     float start[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     if (inputTmx) std::memcpy(start, iTmx, sizeof start);

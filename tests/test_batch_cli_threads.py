@@ -114,3 +114,20 @@ def test_device_list_from_the_environment(tmp_path, tool):
     r = subprocess.run([tool] + _args(tmp_path, out, 3, "0", 4), capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "2 workers on GPU devices 0,0" in open(out / "ProcessingLog.txt").read()
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0"])
+def test_a_failed_library_call_stops_the_batch(tmp_path, tool, devices):
+    """A registration call that fails (the library prints its error and returns non-zero without touching the outputs) must not
+    be papered over with the previous time point's buffers: the tool stops, exits non-zero and writes no result for that
+    time point.  (Found on the GPU: four workers on one device, a failed cost evaluation, a Matrix_k.tmx holding the identity.)"""
+    _series(tmp_path, 6)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", MIL_STUB_FAIL_REG_CALL="3")
+    out = tmp_path / "out_fail"
+    r = subprocess.run([tool] + _args(tmp_path, out, 3, devices, 6), capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert "registration failed (status -1), processing stopped" in r.stdout
+    written = [n for n in _tree(out) if n.startswith("TMX")]
+    assert len(written) < 6  # the failed time point (and whatever would have followed it on that worker) has no matrix file
+    log = open(out / "ProcessingLog.txt").read()
+    assert "registration failed" in log and "Batch processing completed" not in log

@@ -380,6 +380,34 @@ def test_registration_orders_itself_after_pending_stream_work(dev):
         del big
 
 
+def test_concurrent_registrations_share_a_device(api):
+    """Four host threads register on ONE device at the same time (the batch tool with a device list such as 0,0,0,0): every
+    call succeeds and returns what the same call returns alone, bit for bit.  Found with four workers at 512 x 512 x 256: the
+    completion counters of a cost workspace were zeroed with hipMemset on the NULL stream, which is asynchronous to the host
+    and not ordered with the registration's own stream -- under load it landed inside the first evaluations, no workgroup was
+    "last", and the call failed with "the cost kernel did not publish its result"."""
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    pairs = [_shifted_pair(shape=(40, 56, 64), shift=(1.0 + 0.5 * k, -2.0 + 0.25 * k, 0.4 * k)) for k in range(4)]
+    want = [api.reg3d(t, s, aff_method=6, it_limit=400) for t, s in pairs]
+    load = torch.empty((256, 512, 512), device="cuda")
+
+    def work(k):
+        out = []
+        for rep in range(6):  # a fresh workspace (and its zeroing) per call
+            if k == 0:
+                load.normal_()  # the NULL stream stays busy too
+            out.append(api.reg3d(*pairs[k], aff_method=6, it_limit=400))
+        return out
+
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(work, range(4)))
+    for k in range(4):
+        for reg, tmx, rec in got[k]:
+            assert np.array_equal(tmx, want[k][1]), (k, tmx, want[k][1])
+            assert np.array_equal(reg, want[k][0]) and rec[5] == want[k][2][5]
+
+
 # ---------------------------------------------------------------- benchmark size, size-independent properties
 def test_full_size_registration_properties(dev):
     """512x512x256 (BASELINE.json config 4), beside the fixture comparison above: size-independent properties.

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--workers", default="",
                     help="also run our main with this device list (argument 34, e.g. '0,0' = two worker threads sharing "
                          "device 0; '0,1,2,3' on a multi-GPU node) and compare its stacks with the one-worker run")
+    ap.add_argument("--skip-reference", action="store_true", help="do not run the reference's main")
+    ap.add_argument("--repeat-workers", type=int, default=1, help="run the --workers configuration this many times")
     args = ap.parse_args()
 
     import torch
@@ -70,7 +72,7 @@ def main():
     res = {}
     for name, exe in (("reference main, sequential I/O", os.path.join(ROOT, "oracle", "_ref", "cli", "spimFusionBatch")),
                       ("our main, read-ahead + write-behind", os.path.join(ROOT, "microimagelib_amd", "bin", "spimFusionBatch"))):
-        if not os.path.exists(exe):
+        if not os.path.exists(exe) or (args.skip_reference and "reference" in name):
             res[name] = None
             continue
         out = w + "/out_" + ("ref" if "reference" in name else "ours")
@@ -83,21 +85,32 @@ def main():
             print(name, "\n".join(l for l in r.stdout.splitlines() if "ime cost" in l)[-1500:], file=sys.stderr)
         res[name] = {"seconds": round(dt, 3), "time_points_per_s": round(args.time_points / dt, 3)}
     same_workers = None
-    if args.workers:
+    for rep in range(args.repeat_workers if args.workers else 0):
         exe = os.path.join(ROOT, "microimagelib_amd", "bin", "spimFusionBatch")
         out = w + "/out_workers"
+        shutil.rmtree(out, ignore_errors=True)
         t0 = time.perf_counter()
         r = subprocess.run([exe] + cli_args(out, args.workers), capture_output=True, text=True, timeout=1800)
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             raise SystemExit(r.stdout[-1500:] + r.stderr[-1500:])
-        res[f"our main, worker threads on devices {args.workers}"] = {"seconds": round(dt, 3),
-                                                                      "time_points_per_s": round(args.time_points / dt, 3)}
-        same_workers = all(open(f"{w}/out_workers/Decon/Decon_{t}.tif", "rb").read() == open(f"{w}/out_ours/Decon/Decon_{t}.tif", "rb").read()
-                           and open(f"{w}/out_workers/TMX/Matrix_{t}.tmx").read() == open(f"{w}/out_ours/TMX/Matrix_{t}.tmx").read()
-                           for t in range(args.time_points))
+        res[f"our main, worker threads on devices {args.workers}" + (f" (run {rep + 1})" if args.repeat_workers > 1 else "")] = {
+            "seconds": round(dt, 3), "time_points_per_s": round(args.time_points / dt, 3)}
+        same_workers = same_workers is not False
+        for t in range(args.time_points):
+            same_tmx = open(f"{w}/out_workers/TMX/Matrix_{t}.tmx").read() == open(f"{w}/out_ours/TMX/Matrix_{t}.tmx").read()
+            same_tif = open(f"{w}/out_workers/Decon/Decon_{t}.tif", "rb").read() == open(f"{w}/out_ours/Decon/Decon_{t}.tif", "rb").read()
+            if not (same_tmx and same_tif):
+                same_workers = False
+                a, b = api.readtifstack(f"{w}/out_workers/Decon/Decon_{t}.tif"), api.readtifstack(f"{w}/out_ours/Decon/Decon_{t}.tif")
+                print(f"run {rep + 1}, time point {t}: matrix file {'same' if same_tmx else 'DIFFERS'}, decon stack {'same' if same_tif else 'DIFFERS'} "
+                      f"(max abs diff {float(np.abs(a - b).max())}, {int((a != b).sum())} voxels)", file=sys.stderr)
+                if not same_tmx:
+                    print(open(f"{w}/out_workers/TMX/Matrix_{t}.tmx").read(), open(f"{w}/out_ours/TMX/Matrix_{t}.tmx").read(), file=sys.stderr)
+                    print("stderr of the tool:", r.stderr[-3000:], file=sys.stderr)
+                    print("\n".join(l for l in r.stdout.splitlines() if "rror" in l or "libapi" in l or "fail" in l)[-3000:], file=sys.stderr)
     same = None
-    if all(v for k, v in res.items() if "worker" not in k):
+    if all(v for k, v in res.items() if "worker" not in k) and not args.skip_reference:
         same = all(np.array_equal(api.readtifstack(f"{w}/out_ref/Decon/Decon_{t}.tif"),
                                   api.readtifstack(f"{w}/out_ours/Decon/Decon_{t}.tif")) for t in range(args.time_points))
     print(json.dumps({"workload": f"spimFusionBatch CLI, {args.time_points} time points 512x512x256, 16-bit TIFF in/out, "
