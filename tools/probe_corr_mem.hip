@@ -120,6 +120,53 @@ void pattern(const float *__restrict__ tgt, const float *__restrict__ src, unsig
     }
 }
 
+
+// What would lanes that own y-ADJACENT voxels cost?  A lane owns NV voxels (x, y .. y + NV - 1); per step it loads NV target
+// words and gathers the NV + 1 rows y .. y + NV of the new upper plane (the middle rows serve two voxels each): 1 + 1/NV gathers
+// per voxel instead of 2.  Tiles: 64 x, 4 waves x NV rows, 16 z steps.
+template <int NV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void pattern_ypairs(const float *__restrict__ tgt, const float *__restrict__ src, unsigned *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = NX / 64, gy = NY / (4 * NV);
+    const int bx = blockIdx.x % gx, by = (blockIdx.x / gx) % gy, bz = blockIdx.x / (gx * gy);
+    const int x = bx * 64 + lane, y0 = (by * 4 + wave) * NV, z0 = bz * 16;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, PITCH * PY * PZ * 4, 0x00020000);
+    const unsigned row = PITCH * 4, plane = PITCH * PY * 4;
+    unsigned off = (unsigned)(z0 * (int)plane + y0 * (int)row + x * 4);
+    unsigned toff = 4u * ((unsigned)x + NX * ((unsigned)y0 + NY * (unsigned)z0));
+    const char *tb = reinterpret_cast<const char *>(tgt);
+    unsigned acc = 0;
+    u32x2 g[NV + 1], n[NV + 1];
+    unsigned t[NV], tn[NV];
+#pragma unroll
+    for (int r = 0; r <= NV; ++r) g[r] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, (int)(plane + r * row), 0);
+#pragma unroll
+    for (int r = 0; r < NV; ++r) t[r] = *reinterpret_cast<const unsigned *>(tb + toff + r * 4u * NX);
+#pragma unroll 2
+    for (int s = 1; s < 16; ++s) {
+        off += plane; toff += 4u * NX * NY;
+#pragma unroll
+        for (int r = 0; r <= NV; ++r) n[r] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, (int)(plane + r * row), 0);
+#pragma unroll
+        for (int r = 0; r < NV; ++r) tn[r] = *reinterpret_cast<const unsigned *>(tb + toff + r * 4u * NX);
+#pragma unroll
+        for (int r = 0; r <= NV; ++r) acc ^= g[r].x ^ g[r].y;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) acc ^= t[r];
+#pragma unroll
+        for (int r = 0; r <= NV; ++r) g[r] = n[r];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) t[r] = tn[r];
+    }
+#pragma unroll
+    for (int r = 0; r <= NV; ++r) acc ^= g[r].x ^ g[r].y;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) acc ^= t[r];
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(256) void stream(const u32x4 *__restrict__ a, size_t n, unsigned *out) {
     unsigned acc = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -225,6 +272,14 @@ int main() {
         }
         RUNT(0, "none") RUNT(1, "as the cost kernels: two publishes in a row") RUNT(2, "one round: four stores, one wait, two counts")
         RUNT(3, "one round, waves 1-3 leave before it") RUNT(0, "none") RUNT(1, "as the cost kernels: two publishes in a row")
+    }
+    {
+        const float u2 = time_us([&] { hipLaunchKernelGGL((pattern_ypairs<2>), dim3((NX / 64) * (NY / 8) * (NZ / 16)), dim3(256), 0, nullptr, tgt, src, out); }, 20);
+        printf("lanes own 2 y-adjacent voxels (3 gathers per 2 voxels): %7.1f us\n", u2);
+        const float u4 = time_us([&] { hipLaunchKernelGGL((pattern_ypairs<4>), dim3((NX / 64) * (NY / 16) * (NZ / 16)), dim3(256), 0, nullptr, tgt, src, out); }, 20);
+        printf("lanes own 4 y-adjacent voxels (5 gathers per 4 voxels): %7.1f us\n", u4);
+        const float u1 = time_us([&] { hipLaunchKernelGGL((pattern_ypairs<1>), dim3((NX / 64) * (NY / 4) * (NZ / 16)), dim3(256), 0, nullptr, tgt, src, out); }, 20);
+        printf("lanes own 1 voxel (2 gathers per voxel, 64-wide tiles):    %7.1f us\n", u1);
     }
 #define RUNV(OP, LABEL, PER)                                                                                           \
     {                                                                                                                  \
