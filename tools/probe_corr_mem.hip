@@ -27,7 +27,7 @@ constexpr int PY = NY + 2, PZ = NZ + 2;
 
 // MARCHY 0: 16 steps along z at fixed y | 1: 16 steps along y at fixed z.  VALU = dummy dependent VALU instructions per step
 // (0: the pattern alone).
-template <int MARCHY, int VALU, int WAVES_PER_EU, int ORDER = 0, int PARTS = 7, int TAIL = 0>
+template <int MARCHY, int VALU, int WAVES_PER_EU, int ORDER = 0, int PARTS = 7, int TAIL = 0, int DWORDS = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, WAVES_PER_EU)))
 void pattern(const float *__restrict__ tgt, const float *__restrict__ src, unsigned *out, double *partials = nullptr,
              unsigned *counters = nullptr) {
@@ -51,6 +51,12 @@ void pattern(const float *__restrict__ tgt, const float *__restrict__ src, unsig
     auto g = [&](unsigned off, unsigned so) {
         const bool side1 = so != sStep;
         if (!(PARTS & (side1 ? 4 : 2))) return u32x2{off, so};
+        if (DWORDS) {  // the (x0, x1) pair as two 4-byte gathers (the +4 hidden from the compiler, which would fuse them again)
+            unsigned four = 4u;
+            asm volatile("" : "+s"(four));
+            return u32x2{__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, (int)so, 0),
+                         __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, (int)(so + four), 0)};
+        }
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, (int)so, 0);
         return v;
     };
@@ -272,6 +278,12 @@ int main() {
         }
         RUNT(0, "none") RUNT(1, "as the cost kernels: two publishes in a row") RUNT(2, "one round: four stores, one wait, two counts")
         RUNT(3, "one round, waves 1-3 leave before it") RUNT(0, "none") RUNT(1, "as the cost kernels: two publishes in a row")
+    }
+    {
+        const float us = time_us([&] { hipLaunchKernelGGL((pattern<0, 0, 5, 0, 7, 0, 1>), dim3(grid), dim3(256), 0, nullptr, tgt, src, out, nullptr, nullptr); }, 20);
+        printf("march-z, every 8-byte gather as two 4-byte gathers: %7.1f us\n", us);
+        const float us6 = time_us([&] { hipLaunchKernelGGL((pattern<0, 0, 5, 0, 6, 0, 1>), dim3(grid), dim3(256), 0, nullptr, tgt, src, out, nullptr, nullptr); }, 20);
+        printf("march-z, only the gathers, as 4-byte gathers: %7.1f us\n", us6);
     }
     {
         const float u2 = time_us([&] { hipLaunchKernelGGL((pattern_ypairs<2>), dim3((NX / 64) * (NY / 8) * (NZ / 16)), dim3(256), 0, nullptr, tgt, src, out); }, 20);
