@@ -583,47 +583,95 @@ __device__ __forceinline__ void xy_stage_m(float2 *tile, const float2 *tw) {
     }
 }
 
+// Occupancy.  The 64 rows x NH columns of a workgroup live in registers (128 per thread), which left room for two waves per
+// SIMD; two waves spent 31 % of the time both waiting (loads, barriers, LDS round trips).  For NH <= 256 the kernel is built
+// for THREE (<= 168 registers, three / six workgroups per CU):
+//   * PARK = 8 of the 64 values wait in LDS (thread-private slots, 16 KB at NH = 256 -- all that three workgroups leave);
+//   * the fused radix-16 stage runs as radix 2 (across lanes l and l + 32) x radix 8 (in the lane): 8 + 8 instead of
+//     16 + 16 complex temporaries;
+//   * addresses and twiddles of the trip loop are recomputed per trip (hoisted, they were what got spilled).
+// NH = 512 (eight waves per workgroup, 74 KB of tile) stays at two waves per SIMD without parking.
+template <int NH>
+struct XyCfg {
+    static constexpr int occ = NH == 512 ? 2 : 3;
+    static constexpr int park = NH == 512 ? 0 : 8;
+};
+
+// lanes l and l + 32 exchange (v_permlane32_swap):  a' = (a of the lower lanes | b of the LOWER lanes),
+// b' = (a of the UPPER lanes | b of the upper lanes)
+__device__ __forceinline__ void swap32(float2 &a, float2 &b) {
+    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = make_float2(__uint_as_float(x[0]), __uint_as_float(y[0]));
+    b = make_float2(__uint_as_float(x[1]), __uint_as_float(y[1]));
+}
+
+// m / t: reciprocal, two Newton steps, v_div_fixup for the special cases -- the IEEE sequence without its range scaling
+// (6 instead of 10 instructions; 32 divisions per thread and trip were 13 % of the ratio kernel's arithmetic).  Within one
+// unit in the last place of the correctly rounded quotient for |t| in [2^-126, 2^126]; t = 0 gives +-inf like the
+// reference's unguarded division (div3Dkernel).
+__device__ __forceinline__ float xy_div(float m, float t) {
+    float r = __builtin_amdgcn_rcpf(t);
+    r = __builtin_fmaf(__builtin_fmaf(-t, r, 1.0f), r, r);
+    float q = m * r;
+    q = __builtin_fmaf(__builtin_fmaf(-t, q, m), r, q);
+    return __builtin_amdgcn_div_fixupf(q, t, m);
+}
+
 template <int MODE, int NY, int NH>
-__global__ __launch_bounds__(NH, 2) void xy_kernel(XyArgs a) {
+__global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
     constexpr int T = NY / 64;  // length of the y tail = distance between the rows of this workgroup
     constexpr int M = NH / 16;  // length of the LDS stage of the x transform
     constexpr int kPitch = Geo<NH>::pitch;
     constexpr int RB = 16, WP = RB + 1, NX = 2 * NH;  // 16 rows per trip through LDS: tile[position][row]
+    constexpr int PARK = XyCfg<NH>::park, NV = 64 - PARK;
     // position p of the half-length sequence, row r: tile[p * WP + p / M + r] -- the skew keeps the fold / split, which
     // step through the positions M at a time, from hammering two banks (54 % of the LDS cycles were conflicts without it)
     __shared__ float2 tile[NH * WP + 16];
-    __shared__ float2 tw[NH];       // w_NH^k = w_NX^(2k): the packed complex transform
-    __shared__ float2 twx[NH / 2];  // w_NX^k: Hermitian fold / split
+    __shared__ float2 tw[NH];  // w_NH^k = w_NX^(2k): the packed complex transform
+    __shared__ float2 parked[PARK > 0 ? PARK * NH : 1];
     const int tid = threadIdx.x;
+    float2 *park = parked + tid;  // + i * NH: this thread's own slots
     const int n2 = blockIdx.x % T, z = blockIdx.x / T;
     const float2 *twy = tw_y_const<NY>();
     tw[tid] = a.tw_x[2 * tid];
-    if (tid < NH / 2) twx[tid] = a.tw_x[tid];
     // This thread's spectrum column is X[kc] (even columns) or X[NH - kc] (odd), kc = tid / 2; columns 0 / 1 are the packed
-    // (X[0], X[NH]) and X[NH/2].  The element of the half-length sequence it folds to / splits from sits at position pz.
+    // (X[0], X[NH]) and X[NH/2].  The element e = a + 16 b of the half-length sequence it folds to / splits from sits at
+    // position M * slot(a) + pos_M(b): block slot(a) = 2 (a mod 8) + a / 8 of the 16 blocks of length M (the order the
+    // radix-2 x radix-8 fused stage wants its sub-transforms in).
     const int kc = tid >> 1;
     const bool odd = tid & 1;
     const int ez = tid == 1 ? NH / 2 : (odd ? NH - kc : kc);
-    const int pz = M * (ez & 15) + xy_pos_m<M>(ez >> 4);
+    const int pz = M * (2 * (ez & 7) + ((ez >> 3) & 1)) + xy_pos_m<M>(ez >> 4);
     const int pzs = pz * WP + pz / M;  // its place in the skewed tile
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, a.spec_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, a.real_bytes);
     const unsigned voff = (unsigned)tid * 8u;
     const unsigned soff0 = (unsigned)((z * NY + n2) * kPitch) * 8u;  // + m * rstep
     constexpr unsigned rstep = (unsigned)T * kPitch * 8u;
-    // middle stage: this thread owns butterfly i = tid % M (elements n = i + M j, j < 16; real x = 2n, 2n + 1) of row
-    // tid / M of the trip; tile row r is volume row y = n2 + T r + 16 T grp
-    const int bi = tid % M, br = tid / M;
-    const unsigned rvoff = (unsigned)(br * T * NX + 2 * bi) * 4u;
-    const unsigned rsoff0 = (unsigned)((z * NY + n2) * NX) * 4u;  // + grp * 16 T rows, + 2 M j floats
-    constexpr unsigned rgrp = 16u * T * NX * 4u, rj = 2u * M * 4u;
+    // Fused stage: lanes l and l + 32 (h = 0, 1) share the butterflies i = sbi of row srow (+ 8 in the second pass).  Lane h
+    // works on the positions 2 M c + M h + sbi (c < 8: block c, half h), which the radix-8 stage turns into the real-space
+    // elements n = si + 2 M r (x = 2 n, 2 n + 1): a wave's M / E access is 256 contiguous bytes of each of its rows.
+    // Tile row r is volume row y = n2 + T r + 16 T grp.
+    const int slow = tid & 31, sh = (tid >> 5) & 1;
+    const int sbi = slow % M, srow = slow / M + (32 / M) * (tid >> 6);
+    const int si = sbi + M * sh;
+    float2 *sp = tile + si * WP + sh + srow;  // + c * SCS (block c) + 8 (second pass)
+    constexpr int SCS = 2 * M * WP + 2;
+    const unsigned svoff = (unsigned)(srow * T * NX + 2 * si) * 4u;
+    const unsigned rsoff0 = (unsigned)((z * NY + n2) * NX) * 4u;  // + grp * 16 T rows, + pass * 8 T rows, + 4 M r floats
+    constexpr unsigned rgrp = 16u * T * NX * 4u, spass = 8u * T * NX * 4u, srj = 4u * M * 4u;
     float2 v[64];
-    float2 pre[16];  // the trip's slice of M / E (element j of the butterfly), requested one trip ahead
+    float2 pre[16];  // M / E of the trip's two passes
     MIL_STAMP(0);
+    // Hermitian fold / split.  With A = own + oth, B = own - oth (oth = the pair lane's value) both lanes of a pair evaluate
+    // the SAME expressions -- no per-lane selects (they were a fifth of the kernel's arithmetic):
+    //   fold   Z' = (A.x - c1 A.y + c2 B.x,      B.y + c1 B.x + c2 A.y)        c1 = +/- w.x (even / odd lane), c2 = w.y
+    //   split  X  = (A.x / 2 + h1 A.y + h2 B.x,  B.y / 2 - h1 B.x + h2 A.y)    h1 = c1 / 2, h2 = c2 / 2,  w = w_NX^kc
+    const float2 wf = a.tw_x[kc];
+    const float fc1 = odd ? -wf.x : wf.x, fc2 = wf.y, fh1 = 0.5f * fc1, fh2 = 0.5f * fc2;
 #pragma unroll
     for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * rstep);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff0 + q * rj);
     // ---- y inverse head: DIT stages L = NY / 8 (over j2, m = j2 + 8 j1; element i = n2 of its sub-transform) and L = NY
     // (over j1; element i = n2 + T j2)
 #pragma unroll
@@ -649,73 +697,110 @@ __global__ __launch_bounds__(NH, 2) void xy_kernel(XyArgs a) {
         for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
     }
     MIL_STAMP(1);
-    lds_barrier();  // tw, twx
-    const float2 wf = twx[kc];
+    // The rows form a queue: the trip works on its first 16, the results join at the end; its last PARK places are in LDS.
+#pragma unroll
+    for (int i = 0; i < PARK; ++i) park[i * NH] = v[NV + i];
+    lds_barrier();  // tw
     // ---- x^-1 . op . x, sixteen rows per trip (rows m = r + 16 grp).  A real loop: the rows in flight always sit in
-    // v[0..15] and the tile rotates by one group per trip.  (Unrolled, the compiler parks half of the tile in scratch.)
+    // v[0..15] and the queue moves up by one group per trip.  (Unrolled, the compiler parks half of the tile in scratch.)
 #pragma unroll 1
     for (int grp = 0; grp < 64 / RB; ++grp) {
         const unsigned rsoff = rsoff0 + grp * rgrp;
         // Hermitian fold, straight from the registers: the lane pair (2k, 2k + 1) holds (X[k], X[NH-k]); each lane forms
-        // its own element of the packed half-length sequence Z' and drops it at that element's digit-reversed position.
+        // its own element of the packed half-length sequence Z' and drops it at that element's position.
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const float2 own = v[r], oth = swap_pair(own);
-            float2 x = odd ? oth : own, y = odd ? own : oth;  // x = X[k], y = X[NH-k]
-            if (kc == 0) {  // columns 0 / 1: x = (X[0], X[NH]) packed, y = X[NH/2]
-                y = make_float2(x.y, 0.f);
-                x.y = 0.f;
-            }
-            const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
-            const float ux = wf.x * dx + wf.y * dy, uy = wf.x * dy - wf.y * dx;
-            float2 zf = odd ? make_float2(sx + uy, ux - sy) : make_float2(sx - uy, sy + ux);
-            if (tid == 1) zf = make_float2(2.f * own.x, -2.f * own.y);  // Z'[NH/2] = 2 conj(X[NH/2])
-            tile[pzs + r] = zf;
+            const float2 A = c_add(own, oth), B = c_sub(own, oth);
+            tile[pzs + r] = make_float2(A.x - fc1 * A.y + fc2 * B.x, B.y + fc1 * B.x + fc2 * A.y);
         }
+        if (tid < 2) {  // lanes 0 / 1 hold the packed (X[0], X[NH]) and X[NH/2]: their elements are written again
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float2 own = v[r];
+                tile[pzs + r] = tid == 0 ? make_float2(own.x + own.y, own.x - own.y)  // Z'[0]
+                                         : make_float2(2.f * own.x, -2.f * own.y);     // Z'[NH/2] = 2 conj(X[NH/2])
+            }
+        }
+        // M / E of the first pass of the fused stage: in flight during the LDS stage (v[0..15] are free now)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pre[r] = buf_load2(rr, svoff, rsoff + r * srj);
         if (grp == 0) MIL_STAMP(8);
         lds_barrier();
         if (grp == 0) MIL_STAMP(9);
-        xy_stage_m<NH, true, +1>(tile, tw);  // DIT stage(s) of length M; the radix-16 stage of length NH is fused below
+        xy_stage_m<NH, true, +1>(tile, tw);  // DIT stage(s) of length M
         lds_barrier();
         if (grp == 0) MIL_STAMP(10);
-        // ---- last inverse stage, real-space operation, first forward stage on the butterfly's 16 elements
-        {
-            float2 *p = tile + bi * WP + br;
-            float2 t[16];
+        // ---- last inverse stages, real-space operation, first forward stages: radix 2 (sub-transforms of length 2 M, split
+        // over the lanes l and l + 32) and radix 8 (length NH) on 8 elements per lane, two passes of 8 rows
 #pragma unroll
-            for (int j = 0; j < 16; ++j) t[j] = p[j * (M * WP + 1)];
+        for (int ps = 0; ps < 2; ++ps) {
+            float2 *p = sp + 8 * ps;
+            float2 t[8], mm[8];
+            // twiddle addresses and the radix-2 twiddle are recomputed / re-read per pass: hoisted out of the trip loop they
+            // cost ~20 registers, which the compiler then spills
+            int si_l = si, wi_l = 8 * sbi;
+            asm volatile("" : "+v"(si_l), "+v"(wi_l));
+            const float2 wl = tw[wi_l];  // w_2M^sbi
 #pragma unroll
-            for (int k = 1; k < 16; ++k) t[k] = tw_mul<+1>(t[k], tw[bi * k]);
-            dft16<+1>(t);
+            for (int r = 0; r < 8; ++r) mm[r] = pre[8 * ps + r];
+            if (ps == 0) {  // the second pass's M / E
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float2 m = pre[j];
+                for (int r = 0; r < 8; ++r) pre[8 + r] = buf_load2(rr, svoff, rsoff + spass + r * srj);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) t[c] = p[c * SCS];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);  // lower lane: both halves of blocks 0..3, upper: of 4..7
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float2 u = t[c], w = tw_mul<+1>(t[c + 4], wl);
+                t[c] = c_add(u, w);
+                t[c + 4] = c_sub(u, w);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);  // lane h: half h of blocks 0..7
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], tw[si_l * k]);
+            dft8<+1>(t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float2 m = mm[j];
                 if (MODE == kXRatio) {  // div3Dkernel: T = A / T (unguarded)
-                    t[j] = make_float2(m.x / t[j].x, m.y / t[j].y);
+                    t[j] = make_float2(xy_div(m.x, t[j].x), xy_div(m.y, t[j].y));
                 } else {  // multi3Dkernel + maxvalue3Dgpukernel: E = max(E * T, eps)
                     float2 e = make_float2(m.x * t[j].x, m.y * t[j].y);
                     e.x = (e.x > a.eps) ? e.x : a.eps;
                     e.y = (e.y > a.eps) ? e.y : a.eps;
-                    buf_store2(rr, rvoff, rsoff + j * rj, e);
+                    buf_store2(rr, svoff, rsoff + ps * spass + j * srj, e);
                     t[j] = e;
                 }
             }
             if constexpr (MODE != kXUpdateLast) {
-                dft16<-1>(t);
+                dft8<-1>(t);
+                asm volatile("" : "+v"(si_l));
 #pragma unroll
-                for (int k = 1; k < 16; ++k) t[k] = tw_mul<-1>(t[k], tw[bi * k]);
+                for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], tw[si_l * k]);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) p[j * (M * WP + 1)] = t[j];
+                for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float2 u = t[c], w = t[c + 4];
+                    t[c] = c_add(u, w);
+                    t[c + 4] = tw_mul<-1>(c_sub(u, w), wl);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) p[c * SCS] = t[c];
             }
-        }
-        if (grp + 1 < 64 / RB) {  // next trip's M / E: in flight during the forward stages and the next fold
-#pragma unroll
-            for (int q = 0; q < 16; ++q) pre[q] = buf_load2(rr, rvoff, rsoff + rgrp + q * rj);
         }
         if (grp == 0) MIL_STAMP(11);
         if constexpr (MODE == kXUpdateLast) {
 #pragma unroll
-            for (int m = 0; m < 64 - RB; ++m) v[m] = v[m + RB];
+            for (int m = 0; m < NV - RB; ++m) v[m] = v[m + RB];
+#pragma unroll
+            for (int i = 0; i < PARK; ++i) v[NV - RB + i] = park[i * NH];
             lds_barrier();  // the next fold overwrites the tile
             continue;
         }
@@ -723,19 +808,21 @@ __global__ __launch_bounds__(NH, 2) void xy_kernel(XyArgs a) {
         xy_stage_m<NH, false, -1>(tile, tw);  // DIF stage(s) of length M
         lds_barrier();
         if (grp == 0) MIL_STAMP(12);
-        // Hermitian split back into this thread's column: each lane picks up its element Z[k] / Z[NH-k], the pair swaps.
+        // The queue moves up by one trip; then the Hermitian split back into this thread's column: each lane picks up its
+        // element Z[k] / Z[NH-k], the pair swaps.
 #pragma unroll
-        for (int m = 0; m < 64 - RB; ++m) v[m] = v[m + RB];
+        for (int m = 0; m < NV - RB; ++m) v[m] = v[m + RB];
+#pragma unroll
+        for (int i = 0; i < PARK; ++i) v[NV - RB + i] = park[i * NH];
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const float2 own = tile[pzs + r], oth = swap_pair(own);
-            const float2 x = odd ? oth : own, y = (kc == 0) ? x : (odd ? own : oth);  // x = Z[k], y = Z[NH-k] (k = 0: both Z[0])
-            const float sx = x.x + y.x, sy = x.y - y.y, dx = x.x - y.x, dy = x.y + y.y;
-            const float tx = wf.x * dx - wf.y * dy, ty = wf.x * dy + wf.y * dx;
-            float2 o = odd ? make_float2(0.5f * (sx - ty), 0.5f * (-sy - tx)) : make_float2(0.5f * (sx + ty), 0.5f * (sy - tx));
-            if (tid == 0) o = make_float2(0.5f * (sx + ty), 0.5f * (sx - ty));  // (X[0], X[NH]), both real
-            if (tid == 1) o = make_float2(own.x, -own.y);                         // X[NH/2] = conj(Z[NH/2])
-            v[64 - RB + r] = o;
+            const float2 A = c_add(own, oth), B = c_sub(own, oth);
+            float2 o = make_float2(0.5f * A.x + fh1 * A.y + fh2 * B.x, 0.5f * B.y - fh1 * B.x + fh2 * A.y);
+            if (tid < 2) o = tid == 0 ? make_float2(own.x + own.y, own.x - own.y)  // (X[0], X[NH]), both real
+                                      : make_float2(own.x, -own.y);                // X[NH/2] = conj(Z[NH/2])
+            if (r < RB - PARK) v[64 - RB + r] = o;
+            else park[(r - (RB - PARK)) * NH] = o;
         }
         if (grp == 0) MIL_STAMP(13);
         lds_barrier();  // the next fold overwrites the tile
@@ -743,6 +830,8 @@ __global__ __launch_bounds__(NH, 2) void xy_kernel(XyArgs a) {
     }
     MIL_STAMP(3);
     if constexpr (MODE == kXUpdateLast) return;
+#pragma unroll
+    for (int i = 0; i < PARK; ++i) v[NV + i] = park[i * NH];
     // ---- y forward head: DIF stages L = NY (over j1) and L = NY / 8 (over j2)
 #pragma unroll
     for (int j2 = 0; j2 < 8; ++j2) {
