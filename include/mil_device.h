@@ -53,6 +53,11 @@ int mil_align_size(float *d_out, const float *d_in, int ox, int oy, int oz, int 
 int mil_flip3(float *d_out, const float *d_in, int nx, int ny, int nz, void *stream);                             /* flipgpu :1680 */
 int mil_rot_y90(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream);            /* rotbyyaxis :528 */
 int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream);     /* maxprojection :490 */
+/* mip3dgpu (src/apifunc.cpp:576-644) on device memory: projectNum rotations about x (rAxis 1) or y (2), each resampled into the
+ * rotated box and projected along z; d_out receives [projectNum][size3[1]][size3[0]] floats.  d_out == NULL only reports
+ * size3 = {width, height, projectNum}.  Synchronises `stream` before it returns. */
+int mil_mip3d(float *d_out, const float *d_img, int nx, int ny, int nz, int rAxis, long long projectNum, int *size3,
+              void *stream);
 
 /* ---- deconvolution engine -------------------------------------------------- */
 typedef struct mil_decon mil_decon;

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mil_flip3": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),
     "mil_rot_y90": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "mil_max_projection": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "mil_mip3d": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_longlong, C.POINTER(C.c_int), C.c_void_p]),
     "mil_decon_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mil_decon_create_backend": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mil_decon_destroy": (None, [C.c_void_p]),

@@ -13,7 +13,9 @@ path; the only exchange is
 
   * regMode 1: the matrix found on the test time point is broadcast from rank 0
     (12 floats), mirroring "register one, apply to all" (:719-751);
-  * the final gather of the per-time-point XY maximum-intensity projections to rank 0.
+  * the final gather of the per-time-point maximum-intensity projections to rank 0: the XY MIP alone, or all five
+    products the reference writes per time point (XY, YZ, ZX and the 36-angle 3-D MIPs about x and y), device-resident,
+    one record per time point, ONE gather (``gather_mip_stack``).
 
 ``regMode 2`` carries a loop dependence between time points: on several ranks the chain state
 (two matrices, 24 floats) is passed from the owner of one time point to the owner of the next, point
@@ -23,7 +25,9 @@ else overlapped (``_run_chained``).  All volume arithmetic happens in ``libapi.s
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+import threading
+import time
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -55,32 +59,71 @@ def broadcast_matrix(tmx: Optional[np.ndarray], src: int = 0, device="cpu", grou
     return t.cpu().numpy()
 
 
-def gather_mip_stack(local: Dict[int, torch.Tensor], time_points: Sequence[int], mip_shape: Tuple[int, int],
-                     device="cpu", group=None) -> Optional[torch.Tensor]:
-    """Gather per-time-point MIPs (rank-local dict t -> [H, W] float32) into a time-ordered stack on rank 0.
+MipShape = Union[Tuple[int, ...], Dict[str, Tuple[int, ...]]]
+# what the last gather_mip_stack of this process moved (bench.py reports it): seconds include waiting for the slowest rank
+last_gather = {"seconds": 0.0, "bytes_per_time_point": 0, "bytes_received_rank0": 0, "products": []}
 
-    Every rank contributes a fixed-size slab (ceil(n / world) slots, unused slots zero) so a single
-    ``gather`` moves everything; rank 0 re-orders the slots into time order.  Returns [n, H, W] on rank 0,
-    None elsewhere."""
+
+def _products(mip_shape: MipShape):
+    """[(name, shape, floats)] of the projection products one time point contributes, in gather order."""
+    if isinstance(mip_shape, dict):
+        items = [(k, tuple(int(v) for v in shp)) for k, shp in mip_shape.items()]
+    else:
+        items = [(None, tuple(int(v) for v in mip_shape))]
+    return [(k, shp, int(np.prod(shp))) for k, shp in items]
+
+
+def _clone_mips(m):
+    return {k: v.clone() for k, v in m.items()} if isinstance(m, dict) else m.clone()
+
+
+def gather_mip_stack(local: Dict[int, object], time_points: Sequence[int], mip_shape: MipShape,
+                     device="cpu", group=None):
+    """Gather the per-time-point projections into time-ordered stacks on rank 0 -- the ONE exchange of the batch.
+
+    `mip_shape` is either one shape (rank-local dict t -> tensor: the XY MIP) or a dict product -> shape (rank-local dict
+    t -> {product: tensor}): the reference writes five products per time point (src/spim_fusion_batch.cpp:915-940: XY, YZ,
+    ZX maximum projections and the 36-angle 3-D MIPs about x and y, ~43 MB at 512x512x256).  All products of a time point
+    travel as ONE float32 record; every rank contributes a fixed-size slab (ceil(n / world) records, unused ones zero) so a
+    single ``gather`` moves everything and rank 0 re-orders the records into time order.  Returns [n, *shape] (or
+    {product: [n, *shape]}) on rank 0, None elsewhere."""
     rank, world = _world(group)
+    time_points = list(time_points)
     n = len(time_points)
+    prods = _products(mip_shape)
+    rec = sum(c for _, _, c in prods)
     slots = (n + world - 1) // world
     mine = shard_time_points(time_points, rank, world)
-    slab = torch.zeros((max(slots, 1),) + tuple(mip_shape), dtype=torch.float32, device=device)
+    t0 = time.perf_counter()
+    slab = torch.zeros((max(slots, 1), rec), dtype=torch.float32, device=device)
     for i, t in enumerate(mine):
-        slab[i].copy_(local[t])
+        off = 0
+        for name, shp, c in prods:
+            src = local[t] if name is None else local[t][name]
+            if tuple(src.shape) != shp:
+                raise ValueError(f"time point {t}: product {name or 'mip'} has shape {tuple(src.shape)}, expected {shp}")
+            slab[i, off:off + c].copy_(src.reshape(-1))
+            off += c
     if world == 1:
         parts = [slab]
     else:
         parts = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
         dist.gather(slab, gather_list=parts, dst=0, group=group)
-        if rank != 0:
-            return None
-    out = torch.empty((n,) + tuple(mip_shape), dtype=torch.float32, device=device)
+    last_gather.update(seconds=time.perf_counter() - t0, bytes_per_time_point=4 * rec,
+                       bytes_received_rank0=4 * rec * (n - len(mine)) if rank == 0 else 0,
+                       products=[name or "xy" for name, _, _ in prods])
+    if rank != 0:
+        return None
+    out = {name: torch.empty((n,) + shp, dtype=torch.float32, device=device) for name, shp, _ in prods}
+    index = {t: k for k, t in enumerate(time_points)}
     for r in range(world):
         for i, t in enumerate(shard_time_points(time_points, r, world)):
-            out[list(time_points).index(t)].copy_(parts[r][i])
-    return out
+            off = 0
+            for name, shp, c in prods:
+                out[name][index[t]].copy_(parts[r][i, off:off + c].reshape(shp))
+                off += c
+    last_gather["seconds"] = time.perf_counter() - t0
+    return out if isinstance(mip_shape, dict) else out[None]
 
 
 # --------------------------------------------------------------------------- registration policy
@@ -193,26 +236,43 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
         mine = shard_time_points(time_points, rank, world)
         dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
 
+        stop = threading.Event()  # set by the first lane that fails: the others finish their time point and return
+
         def lane(l):
             if dev_index is not None:
                 torch.cuda.set_device(dev_index)  # the current device is per thread
             pol = dataclasses.replace(policy)
-            for j, t in enumerate(mine[l::lanes]):
-                a, b = load_pair(t)
-                b_reg, tmx, rec = register_pair(pol, reg_fn, check_fn, a, b, first=(j == 0))
-                decon, mip = fuse_list[l](a, b_reg, t)
-                local[t] = mip.clone()
-                if sink is not None:
-                    sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
+            try:
+                for j, t in enumerate(mine[l::lanes]):
+                    if stop.is_set():
+                        return
+                    a, b = load_pair(t)
+                    b_reg, tmx, rec = register_pair(pol, reg_fn, check_fn, a, b, first=(j == 0))
+                    decon, mip = fuse_list[l](a, b_reg, t)
+                    local[t] = _clone_mips(mip)
+                    if sink is not None:
+                        sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
+            except BaseException:
+                stop.set()
+                raise
 
+        # A failing lane stops the others at their next time point; its exception is raised once all lanes have drained.
+        # Under torch.distributed the healthy RANKS would then wait in the gather for ever: a rank that raises here must
+        # take the process group down (let the exception end the process -- torch.distributed.run then stops the others).
         with concurrent.futures.ThreadPoolExecutor(max_workers=lanes) as pool:
-            for f in [pool.submit(lane, l) for l in range(lanes)]:
+            futures = [pool.submit(lane, l) for l in range(lanes)]
+            concurrent.futures.wait(futures, return_when=concurrent.futures.FIRST_EXCEPTION)
+            stop_now = any(f.done() and f.exception() is not None for f in futures)
+            if stop_now:
+                stop.set()
+            concurrent.futures.wait(futures)
+            for f in futures:
                 f.result()
         return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
 
     def finish(a, b_reg, t, tmx, rec):
         decon, mip = fuse_pair(a, b_reg, t)
-        local[t] = mip.clone() if overlap else mip
+        local[t] = _clone_mips(mip) if overlap else mip
         if sink is not None:
             sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
 
@@ -294,11 +354,16 @@ class FusionPipeline:
     """reg3d -> decon_dualview -> XY MIP on device-resident volumes of one GPU (libapi.so kernels only)."""
 
     def __init__(self, shape, psf_a: torch.Tensor, psf_b: torch.Tensor, iters: int, psf_a_bp: Optional[torch.Tensor] = None,
-                 psf_b_bp: Optional[torch.Tensor] = None):
+                 psf_b_bp: Optional[torch.Tensor] = None, mips: str = "xy", project_num: int = 36):
+        """mips = "xy": fuse_pair returns the XY MIP (a tensor); "all": the five projection products the reference writes
+        per time point (src/spim_fusion_batch.cpp:915-940, projectNum 36 as it hard-codes) as a dict, see `mip_shape`."""
         from . import device as mdev
         self._mdev = mdev
         self.shape = tuple(int(s) for s in shape)
         self.iters = int(iters)
+        if mips not in ("xy", "all"):
+            raise ValueError("mips must be 'xy' or 'all'")
+        self.mips, self.project_num = mips, int(project_num)
         self.engine = mdev.DeconEngine(self.shape)
         # four OTFs once per rank (the reference recomputes them for every time point, src/api_decon.cpp:524-547)
         self.otf_a = self.engine.gen_otf(psf_a)
@@ -333,8 +398,27 @@ class FusionPipeline:
         self.engine.init_dual(A, B, self.estimate)
         self.engine.run_dual(self.estimate, A, B, self.otf_a, self.otf_b, self.bp_a, self.bp_b, self.iters)
         self.engine.sync()
-        mip = self._mdev.max_projection(self.estimate, 1)
-        return self.estimate, mip
+        return self.estimate, self.project(self.estimate)
+
+    @property
+    def mip_shape(self):
+        """What `gather_mip_stack` needs: the XY shape, or product -> shape for mips="all" (mp2dgpu / mip3dgpu layouts,
+        src/apifunc.cpp:485-505, 576-644)."""
+        nz, ny, nx = self.shape
+        if self.mips == "xy":
+            return (ny, nx)
+        rot_x = int(round(np.sqrt(float(ny * ny + nz * nz))))  # rotation about x: the y-z diagonal
+        rot_y = int(round(np.sqrt(float(nx * nx + nz * nz))))
+        return {"xy": (ny, nx), "yz": (nz, ny), "zx": (nx, nz), "mip3d_x": (self.project_num, rot_x, nx),
+                "mip3d_y": (self.project_num, ny, rot_y)}
+
+    def project(self, vol: torch.Tensor):
+        """The projections of one deconvolved volume, device-resident."""
+        if self.mips == "xy":
+            return self._mdev.max_projection(vol, 1)
+        return {"xy": self._mdev.max_projection(vol, 1), "yz": self._mdev.max_projection(vol, 3),
+                "zx": self._mdev.max_projection(vol, 2), "mip3d_x": self._mdev.mip3d(vol, 1, self.project_num),
+                "mip3d_y": self._mdev.mip3d(vol, 2, self.project_num)}
 
     def close(self):
         self.engine.close()

@@ -124,20 +124,32 @@ extern "C" int mp2dgpu(float *h_MP, unsigned int *sizeMP, float *h_img, unsigned
 
 namespace {
 
-// One rotation series: resample into the rotated box, project along z, store the plane.
-void mip_series(float *h_out, const float *d_img, Dims img, Dims rot_box, int axis, long long project_num,
+// One rotation series: resample into the rotated box, project along z, keep the plane -- in device memory (d_out, one plane
+// per angle) or, for the host-pointer entry points, copied out plane by plane like the reference (src/apifunc.cpp:610-618).
+void mip_series(float *h_out, float *d_out, const float *d_img, Dims img, Dims rot_box, int axis, long long project_num,
                 float project_step, hipStream_t s) {
     const size_t plane = (size_t)rot_box.nx * rot_box.ny;
-    DeviceBuffer<float> d_rot((size_t)rot_box.count()), d_proj(plane);
+    DeviceBuffer<float> d_rot((size_t)rot_box.count()), d_proj(d_out ? 0 : plane);
     for (long long i = 0; i < project_num; ++i) {
         const float angle = project_step * (float)(int)i;
         k::Affine12 m;
         rot2matrix(m.m, angle, img.nx, img.ny, img.nz, axis);
         k::affine_resample(d_rot.get(), d_img, rot_box, img, m, s);
-        k::max_projection(d_proj.get(), d_rot.get(), rot_box, 1, s);
-        MIL_HIP(hipMemcpyAsync(h_out + plane * (size_t)i, d_proj.get(), plane * sizeof(float), hipMemcpyDeviceToHost, s));
+        float *proj = d_out ? d_out + plane * (size_t)i : d_proj.get();
+        k::max_projection(proj, d_rot.get(), rot_box, 1, s);
+        if (h_out) MIL_HIP(hipMemcpyAsync(h_out + plane * (size_t)i, proj, plane * sizeof(float), hipMemcpyDeviceToHost, s));
     }
-    MIL_HIP(hipStreamSynchronize(s));
+    MIL_HIP(hipStreamSynchronize(s));  // d_rot is freed on return
+}
+
+// rotated box of mip3dgpu (src/apifunc.cpp:582-590): the rotation axis keeps its extent, the other two become the diagonal
+Dims mip3d_box(Dims d, int axis) {
+    if (axis == 1) {
+        const long long rot = (long long)std::round(std::sqrt((double)(d.ny * d.ny + d.nz * d.nz)));
+        return Dims{d.nx, rot, rot};
+    }
+    const long long rot = (long long)std::round(std::sqrt((double)(d.nx * d.nx + d.nz * d.nz)));
+    return Dims{rot, d.ny, rot};
 }
 
 }  // namespace
@@ -147,24 +159,29 @@ extern "C" int mip3dgpu(float *h_MP, unsigned int *sizeMP, float *h_img, unsigne
     if (rAxis != 1 && rAxis != 2) return -1;  // reference src/apifunc.cpp:590-591
     return guarded("mip3dgpu", [&]() -> int {
         const Dims d{(long long)sizeImg[0], (long long)sizeImg[1], (long long)sizeImg[2]};
-        long long sr, rot;
-        Dims box;
-        if (rAxis == 1) {
-            sr = d.nx;
-            rot = (long long)std::round(std::sqrt((double)(d.ny * d.ny + d.nz * d.nz)));
-            box = Dims{sr, rot, rot};
-        } else {
-            sr = d.ny;
-            rot = (long long)std::round(std::sqrt((double)(d.nx * d.nx + d.nz * d.nz)));
-            box = Dims{rot, sr, rot};
-        }
+        const Dims box = mip3d_box(d, rAxis);
         const float step = (float)(3.14159 * 2 / (float)projectNum);  // :597
         StreamGuard sg;
         DeviceBuffer<float> d_img((size_t)d.count());
         MIL_HIP(hipMemcpyAsync(d_img.get(), h_img, (size_t)d.count() * sizeof(float), hipMemcpyHostToDevice, sg.s));
-        mip_series(h_MP, d_img.get(), d, box, rAxis, projectNum, step, sg.s);
-        if (rAxis == 1) { sizeMP[0] = sr; sizeMP[1] = rot; sizeMP[2] = (unsigned)projectNum; }
-        else { sizeMP[0] = rot; sizeMP[1] = sr; sizeMP[2] = (unsigned)projectNum; }
+        mip_series(h_MP, nullptr, d_img.get(), d, box, rAxis, projectNum, step, sg.s);
+        sizeMP[0] = (unsigned)box.nx; sizeMP[1] = (unsigned)box.ny; sizeMP[2] = (unsigned)projectNum;
+        return 0;
+    });
+}
+
+// Device-pointer form (include/mil_device.h): the stack stays in HBM -- what the process-per-GPU batch driver gathers over
+// RCCL (microimagelib_amd/batch.py).  Same arithmetic, same planes as mip3dgpu.
+extern "C" int mil_mip3d(float *d_out, const float *d_img, int nx, int ny, int nz, int rAxis, long long projectNum,
+                         int *size3, void *stream) {
+    if ((rAxis != 1 && rAxis != 2) || projectNum < 1) return -1;
+    return guarded("mil_mip3d", [&]() -> int {
+        const Dims d{(long long)nx, (long long)ny, (long long)nz};
+        const Dims box = mip3d_box(d, rAxis);
+        if (size3) { size3[0] = (int)box.nx; size3[1] = (int)box.ny; size3[2] = (int)projectNum; }
+        if (!d_out) return 0;  // size query
+        mip_series(nullptr, d_out, d_img, d, box, rAxis, projectNum, (float)(3.14159 * 2 / (float)projectNum),
+                   (hipStream_t)stream);
         return 0;
     });
 }
@@ -181,12 +198,12 @@ extern "C" int mp3dgpu(float *h_MP, unsigned int *sizeMP, float *h_img, unsigned
         DeviceBuffer<float> d_img((size_t)d.count());
         MIL_HIP(hipMemcpyAsync(d_img.get(), h_img, (size_t)d.count() * sizeof(float), hipMemcpyHostToDevice, sg.s));
         if (flagXaxis) {
-            mip_series(h_MP, d_img.get(), d, Dims{d.nx, rot_y, rot_y}, 1, projectNum, step, sg.s);
+            mip_series(h_MP, nullptr, d_img.get(), d, Dims{d.nx, rot_y, rot_y}, 1, projectNum, step, sg.s);
             sizeMP[0] = d.nx; sizeMP[1] = rot_y; sizeMP[2] = projectNum;
         }
         if (flagYaxis) {
             const size_t y_start = (size_t)d.nx * rot_y * projectNum;  // :553 (offset applies even without X)
-            mip_series(h_MP + y_start, d_img.get(), d, Dims{rot_x, d.ny, rot_x}, 2, projectNum, step, sg.s);
+            mip_series(h_MP + y_start, nullptr, d_img.get(), d, Dims{rot_x, d.ny, rot_x}, 2, projectNum, step, sg.s);
             sizeMP[3] = rot_x; sizeMP[4] = d.ny; sizeMP[5] = projectNum;
         }
         return 0;

@@ -104,6 +104,17 @@ def max_projection(a: torch.Tensor, direction: int, stream=None):
     return out
 
 
+def mip3d(a: torch.Tensor, r_axis: int, project_num: int, stream=None):
+    """``mip3dgpu`` on a device volume: stack [projectNum][h][w] in HBM (rotations about x: r_axis 1, about y: 2)."""
+    import ctypes as C
+    lib = _lib.load()
+    size3 = (C.c_int * 3)()
+    _check(lib.mil_mip3d(None, _ptr(a), *_dims(a), int(r_axis), int(project_num), size3, _stream_ptr(stream)), "mil_mip3d")
+    out = torch.empty((int(project_num), size3[1], size3[0]), dtype=torch.float32, device=a.device)
+    _check(lib.mil_mip3d(_ptr(out), _ptr(a), *_dims(a), int(r_axis), int(project_num), size3, _stream_ptr(stream)), "mil_mip3d")
+    return out
+
+
 def affine_resample(src: torch.Tensor, m12, out_shape, stream=None):
     out = torch.empty(tuple(out_shape), dtype=torch.float32, device=src.device)
     m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)

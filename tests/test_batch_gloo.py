@@ -275,3 +275,83 @@ def test_lanes_process_time_points_concurrently_with_the_same_results():
     assert results[1] == results[2] == results[3]
     with pytest.raises(ValueError):
         batch.run_sharded(tps, lambda t: (t, t), [None, None], batch.RegPolicy(reg_mode=2), None, None, MIP_SHAPE, lanes=2)
+
+
+# ---- all five projection products of a time point in one gather (src/spim_fusion_batch.cpp:915-940)
+PRODUCTS = {"xy": (4, 6), "yz": (3, 4), "zx": (6, 3), "mip3d_x": (5, 5, 6), "mip3d_y": (5, 4, 7)}
+
+
+def _product_values(t):
+    return {k: torch.arange(int(np.prod(s)), dtype=torch.float32).reshape(s) * (i + 1) + 1000.0 * t
+            for i, (k, s) in enumerate(PRODUCTS.items())}
+
+
+def _products_worker(rank, world, port, outdir, reg_mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tps = [3, 4, 5, 6, 7]
+        stacks = batch.run_sharded(tps, lambda t: (t, t), lambda a, b, t: (None, _product_values(t)),
+                                   batch.RegPolicy(reg_mode=reg_mode, reg_choice=2), _fake_reg([]), lambda m: True, PRODUCTS)
+        if rank == 0:
+            torch.save({"stacks": stacks, "gather": dict(batch.last_gather)}, os.path.join(outdir, "stacks.pt"))
+        else:
+            assert stacks is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("reg_mode", [3, 2])
+def test_all_projection_products_two_ranks_match_single_rank(tmp_path, reg_mode):
+    """XY, YZ, ZX and both 36-angle 3-D MIP stacks travel as ONE record per time point in ONE gather; rank 0 ends up with
+    the five time-ordered stacks of the single-rank run (also through the regMode-2 token ring)."""
+    port = _free_port()
+    mp.spawn(_products_worker, args=(2, port, str(tmp_path), reg_mode), nprocs=2, join=True)
+    got = torch.load(tmp_path / "stacks.pt")
+    tps = [3, 4, 5, 6, 7]
+    single = batch.run_sharded(tps, lambda t: (t, t), lambda a, b, t: (None, _product_values(t)),
+                               batch.RegPolicy(reg_mode=reg_mode, reg_choice=2), _fake_reg([]), lambda m: True, PRODUCTS)
+    assert set(got["stacks"]) == set(PRODUCTS) == set(single)
+    for k, shp in PRODUCTS.items():
+        assert tuple(got["stacks"][k].shape) == (len(tps),) + shp
+        assert torch.equal(got["stacks"][k], single[k])
+        for i, t in enumerate(tps):
+            assert torch.equal(single[k][i], _product_values(t)[k])
+    rec = sum(int(np.prod(s)) for s in PRODUCTS.values())
+    assert got["gather"]["bytes_per_time_point"] == 4 * rec
+    assert got["gather"]["bytes_received_rank0"] == 4 * rec * 2  # time points 4 and 6 came from rank 1
+    assert got["gather"]["products"] == list(PRODUCTS)
+
+
+def test_gather_rejects_a_product_of_the_wrong_shape():
+    with pytest.raises(ValueError, match="mip3d_x"):
+        bad = _product_values(3)
+        bad["mip3d_x"] = bad["mip3d_x"][:, :, :5]
+        batch.gather_mip_stack({3: bad}, [3], PRODUCTS)
+
+
+def test_a_failing_lane_stops_the_others_at_their_next_time_point():
+    """lanes=2: the first exception sets a stop flag; the healthy lane finishes the time point it is on and returns, the
+    exception is raised after the lanes have drained (it used to surface only after ALL remaining time points)."""
+    import threading
+    import time as _time
+    done, lock = [], threading.Lock()
+
+    def reg_fn(target, source, i_tmx, reg_choice, aff_method, input_tmx, ftol, it_limit):
+        if int(target) == 21:
+            raise RuntimeError("registration of time point 21 failed")
+        _time.sleep(0.05)
+        with lock:
+            done.append(int(target))
+        tmx = np.eye(3, 4, dtype=np.float32).reshape(12)
+        rec = np.zeros(11, dtype=np.float32)
+        rec[3] = 0.9
+        return source, tmx, rec
+
+    fuse = [lambda a, b, t: (None, torch.zeros(MIP_SHAPE))] * 2
+    with pytest.raises(RuntimeError, match="time point 21"):
+        batch.run_sharded(list(range(20, 60)), lambda t: (t, t), fuse, batch.RegPolicy(reg_mode=3, reg_choice=2), reg_fn,
+                          lambda m: True, MIP_SHAPE, lanes=2)
+    assert len(done) <= 2, done  # lane 0 (20, 22, ...) stopped right away instead of working through 20 time points

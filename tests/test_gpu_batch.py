@@ -103,3 +103,30 @@ def test_overlapped_pipeline_equals_serial():
     for a, b in zip(runs[False][1], runs[True][1]):
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert a[3][5] == b[3][5]
+
+
+def test_pipeline_projection_products_match_mp2dgpu_and_mip3dgpu():
+    """FusionPipeline(mips="all") leaves the five products of a time point in HBM (what the batch gathers over RCCL): the
+    same bits as the host-pointer entry points mp2dgpu / mip3dgpu (include/libapi.h) give on the same volume."""
+    import torch
+    from microimagelib_amd import api, batch
+    shape = (20, 36, 48)
+    psf = torch.from_numpy(do.gaussian_psf((7, 7, 7), (1.5, 1.2, 1.2))).cuda()
+    pipe = batch.FusionPipeline(shape, psf, psf, iters=1, mips="all", project_num=36)
+    try:
+        vol = torch.from_numpy(do.blob_volume(shape, n_blobs=10, seed=11)).cuda()
+        got = pipe.project(vol)
+        assert {k: tuple(v.shape) for k, v in got.items()} == pipe.mip_shape
+        xy, yz, zx = api.mp2dgpu(vol.cpu().numpy())
+        assert np.array_equal(got["xy"].cpu().numpy(), xy)
+        assert np.array_equal(got["yz"].cpu().numpy(), yz)
+        assert np.array_equal(got["zx"].cpu().numpy(), zx)
+        for name, axis in (("mip3d_x", 1), ("mip3d_y", 2)):
+            want = api.mip3dgpu(vol.cpu().numpy(), axis, 36)
+            assert got[name].shape == want.shape and np.array_equal(got[name].cpu().numpy(), want), name
+        # and through the gather of a one-rank world: time-ordered stacks per product
+        stacks = batch.gather_mip_stack({7: got, 5: got}, [5, 7], pipe.mip_shape, device="cuda")
+        assert all(torch.equal(stacks[k][0], got[k]) and torch.equal(stacks[k][1], got[k]) for k in got)
+        assert batch.last_gather["bytes_per_time_point"] == 4 * sum(v.numel() for v in got.values())
+    finally:
+        pipe.close()
