@@ -10,6 +10,10 @@ GPU, inputs resident in HBM (BASELINE.json configs[1]).  N > 1: one process per 
 collective on the data path; the only exchange is the gather of the XY maximum-intensity
 projections to rank 0 after the timed region.
 
+`python bench.py --gpus N` from a plain shell starts the N ranks ITSELF (a child `python -m torch.distributed.run
+--nproc-per-node N ... bench.py ...` spawned before anything touches the GPU; its output is passed through and its exit
+status returned); under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      HBM roofline of the dominant kernel (z_conv of the fused backend: the top symbol of the rocprofv3
                 kernel stats), timed with HIP events on the engine's stream inside the timed region; the other
@@ -99,6 +103,215 @@ def cpu_baseline(img_host, psf_host, iters, threads):
     return iters / loop_s, loop_s, whole
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` called directly: run the N ranks as a CHILD process tree (torch.distributed.run, one rank per
+    GPU, rendezvous on 127.0.0.1) and hand back its exit status.  Nothing here has touched the GPU or imported torch, and
+    the launcher is a child, never an exec -- a process that has initialised the GPU must not be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    print("bench.py: starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Argument plumbing, rendezvous and the collectives of the timed region on the CPU (gloo): no GPU, no measurement.
+    Rank 0 prints one JSON line; used by tests/test_bench_launch.py so that the self-launching path cannot rot."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("MIL_BENCH_DRY_RUN_FAIL") == str(rank):  # test hook: a rank that dies must fail the whole command
+        raise SystemExit(3)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        slowest = float(t.item())
+        parts = [torch.empty(4) for _ in range(world)] if rank == 0 else None
+        dist.gather(torch.full((4,), float(rank)), gather_list=parts, dst=0)
+        gathered = [float(p[0]) for p in parts] if rank == 0 else None
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        slowest, gathered = 1.0, [0.0]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "requested_gpus": args.gpus, "steps": args.steps,
+                          "warmup": args.warmup, "max_over_ranks": slowest, "gathered_ranks": gathered,
+                          "local_rank_env": os.environ.get("LOCAL_RANK")}), flush=True)
+
+
+def timed(torch, fn, reps=5):
+    """Average seconds of fn() on the current stream (HIP events), after one untimed call."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def auxiliary_kernels(torch, mdev, eng, img, psf):
+    """The kernels either side of the RL loop and of the cost evaluation ("Resample: read R + write R"; f-row
+    kernels), each with its algorithmic bytes, GB/s and fraction of the HBM peak; kernel names as rocprofv3 prints them."""
+    nz, ny, nx = img.shape
+    R = 4 * img.numel()
+
+    def row(kernel, seconds, nbytes, note=None):
+        d = {"kernel": kernel, "ms": round(seconds * 1e3, 4), "algorithmic_bytes": int(nbytes),
+             "hbm_gbs": round(nbytes / seconds / 1e9, 1), "frac_of_peak": round(nbytes / seconds / 1e9 / HBM_PEAK_GBS, 4)}
+        if note:
+            d["note"] = note
+        return d
+    out = {}
+    ident = np.eye(3, 4, dtype=np.float32).reshape(12)
+    c, s = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+    lin = 1.02 * np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+    ctr = np.array([nx / 2, ny / 2, nz / 2])
+    m3 = np.concatenate([lin, (ctr - lin @ ctr + np.array([5.0, -3.0, 2.0]))[:, None]], axis=1).astype(np.float32).reshape(12)
+    dst = torch.empty_like(img)
+    lib = mdev._lib.load()
+
+    def resample(m):
+        mm = np.ascontiguousarray(m, dtype=np.float32)
+        return lambda: mdev._check(lib.mil_affine_resample(dst.data_ptr(), img.data_ptr(), nx, ny, nz, nx, ny, nz,
+                                                           mm.ctypes.data_as(mdev._lib.c_float_p),
+                                                           int(torch.cuda.current_stream().cuda_stream)), "mil_affine_resample")
+    out["resample_identity"] = row("resample_kernel<false>", timed(torch, resample(ident)), 2 * R, "affineTransform, read R + write R")
+    out["resample_3deg_2pct"] = row("resample_kernel<false>", timed(torch, resample(m3)), 2 * R, "rotation 3 deg about y, scale 1.02, shift")
+    # mip3dgpu: 36 x (resample into the rotated box + z projection); bytes per angle = read R (source) + write and read
+    # the rotated box + write the plane
+    for axis in (1, 2):
+        box = (nx, round((ny * ny + nz * nz) ** 0.5), round((ny * ny + nz * nz) ** 0.5)) if axis == 1 else \
+              (round((nx * nx + nz * nz) ** 0.5), ny, round((nx * nx + nz * nz) ** 0.5))
+        per_angle = R + 2 * 4 * box[0] * box[1] * box[2] + 4 * box[0] * box[1]
+        sec = timed(torch, lambda: mdev.mip3d(img, axis, 36), reps=2)
+        out[f"mip3d_axis{axis}_36_angles"] = row("resample_kernel<false> + max_projection_kernel (x36)", sec, 36 * per_angle,
+                                                 f"rotated box {box[0]}x{box[1]}x{box[2]}")
+    for d, name in ((1, "xy"), (3, "yz"), (2, "zx")):
+        sec = timed(torch, lambda: mdev.max_projection(img, d))
+        out[f"max_projection_{name}"] = row("max_projection_kernel", sec, R, "mp2dgpu plane: read R")
+    small = img[:nz - 6, :ny - 12, :nx - 12].contiguous()  # 500 x 500 x 250 in a 512 x 512 x 256 box
+    padded = mdev.pad_stack(small, img.shape)
+    out["pad_stack_500x500x250"] = row("pad_stack_kernel", timed(torch, lambda: mdev.pad_stack(small, img.shape)), 4 * small.numel() + R,
+                                       "padstackgpu: read image + write box (torch allocation of the output included)")
+    out["crop_500x500x250"] = row("crop_kernel", timed(torch, lambda: mdev.crop_stack(padded, small.shape)), 2 * 4 * small.numel(),
+                                  "cropgpu: read + write image")
+    out["rot_y90"] = row("rot_y90_kernel", timed(torch, lambda: mdev.rot_y90(img, 1)), 2 * R, "imoperation3D +90 deg about y")
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.gen_otf(psf)
+    eng.sync()
+    out["gen_otf"] = {"kernels": "reduce_kernel + pad_psf_kernel + forward transform (3 kernels)",
+                      "ms": round((time.perf_counter() - t0) / 3 * 1e3, 3),
+                      "note": "genOTFgpu of a 64x64x64 PSF into the 512x512x256 box, incl. allocation of the OTF"}
+    return out
+
+
+def batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, psf_a, psf_b, fence, distributed):
+    """BASELINE.json configs[4] per regMode: what ">= 7x at 8 GPUs" is judged on.  regMode 3 (independent time points,
+    `lanes` in flight per GPU), regMode 2 (the chained mode sh_spimFusionBatch.sh:21 runs: token ring over the ranks) and
+    regMode 3 with 16-bit TIFF stacks read and written inside the timed region.  Every time point ends in the FIVE projection
+    products of the reference; they are gathered to rank 0 in one exchange whose seconds and bytes are reported."""
+    c2, s2 = np.cos(np.deg2rad(2.0)), np.sin(np.deg2rad(2.0))
+    lin2 = np.array([[c2, 0, -s2], [0, 1, 0], [s2, 0, c2]])
+    centre2 = np.array([SHAPE[2] / 2, SHAPE[1] / 2, SHAPE[0] / 2])
+    known2 = np.concatenate([lin2, (centre2 - lin2 @ centre2 + np.array([3.0, -2.0, 1.0]))[:, None]],
+                            axis=1).astype(np.float32).reshape(12)
+    # same object as view A, other PSF, displaced by 2 deg + shift
+    view_b = mdev.affine_resample(synth_volume(torch, SHAPE, (2.5, 2.5, 6.0), seed=100 + rank), known2, SHAPE)
+    lanes = max(1, args.batch_lanes)
+    pipes = [batch.FusionPipeline(SHAPE, psf_a, psf_b, iters=20, mips="all") for _ in range(lanes)]
+    pipe = pipes[0]
+    n_tp = args.batch_time_points_per_gpu * world
+    out = {}
+
+    def policy(mode):
+        return batch.RegPolicy(reg_mode=mode, reg_choice=2, aff_method=6, ftol=1e-4, it_limit=3000)
+
+    def measure(key, workload, run, warm_tps, extra=None):
+        run(warm_tps)  # warm-up: plans, OTFs, clocks
+        fence()
+        tb = time.perf_counter()
+        stacks = run(list(range(n_tp)))
+        fence()
+        sec = time.perf_counter() - tb
+        if distributed:
+            tt = torch.tensor([sec], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sec = float(tt.item())
+        if rank == 0:
+            g = batch.last_gather
+            out[key] = dict({"workload": workload, "time_points": n_tp, "time_points_per_s": round(n_tp / sec, 3),
+                             "elapsed_s": round(sec, 3),
+                             "mip_gather": {"seconds_rank0": round(g["seconds"], 4), "products": g["products"],
+                                            "bytes_per_time_point": g["bytes_per_time_point"],
+                                            "bytes_received_rank0": g["bytes_received_rank0"]},
+                             "mip_stacks": {k: list(v.shape) for k, v in stacks.items()}}, **(extra or {}))
+
+    base = ("reg3d (affMethod 6) + joint dual-view RL (20 it) + XY / YZ / ZX MIPs + 36-angle 3-D MIPs about x and y per time "
+            "point, 512x512x256, all projections gathered to rank 0")
+    common = dict(load_pair=lambda t: (img_a, view_b), reg_fn=pipe.reg_fn, check_fn=pipe.check_fn, mip_shape=pipe.mip_shape,
+                  device=coll_dev)
+    if lanes > 1:
+        # `lanes` time points in flight per GPU, one host thread each with its own engine: the kernels of one fill the host
+        # round trips between the dependent cost evaluations of the other
+        run3 = lambda tps: batch.run_sharded(tps, fuse_pair=[p.fuse_pair for p in pipes], policy=policy(3), lanes=lanes, **common)
+    else:
+        run3 = lambda tps: batch.run_sharded(tps, fuse_pair=pipe.fuse_pair, policy=policy(3), overlap=True, **common)
+    measure("regmode3", "spimFusionBatch loop, regMode 3 (independent time points): " + base + "; views resident in HBM",
+            run3, list(range(world * lanes)), {"time_points_in_flight_per_gpu": lanes})
+    run2 = lambda tps: batch.run_sharded(tps, fuse_pair=pipe.fuse_pair, policy=policy(2), **common)
+    measure("regmode2", "spimFusionBatch loop, regMode 2 (chained start matrices, the mode of sh_spimFusionBatch.sh:21; token "
+            "ring over the ranks, registrations serial by definition): " + base + "; views resident in HBM",
+            run2, list(range(world)), {"time_points_in_flight_per_gpu": 1})
+    if args.batch_tiff_dir:
+        from microimagelib_amd import api
+        tdir = os.path.join(args.batch_tiff_dir, f"rank{rank}")
+        os.makedirs(tdir, exist_ok=True)
+        for name, vol in (("SPIMA", img_a), ("SPIMB", view_b)):  # setup, not timed
+            api.writetifstack(os.path.join(tdir, f"{name}.tif"), vol.clamp(0, 65535).cpu().numpy(), bits=16)
+        bufs = torch.empty((3, 2) + SHAPE, dtype=torch.float32).pin_memory()  # overlap: three pairs are live at once
+        outb = torch.empty(SHAPE, dtype=torch.float32).pin_memory()
+        calls = [0]
+
+        def load_tiff(t):
+            buf = bufs[calls[0] % 3]
+            calls[0] += 1
+            for i, name in enumerate(("SPIMA", "SPIMB")):
+                api.readtifstack(os.path.join(tdir, f"{name}.tif"), out=buf[i].numpy())
+            a, b = buf[0].cuda(non_blocking=True), buf[1].cuda(non_blocking=True)
+            torch.cuda.current_stream().synchronize()  # the library's streams do not wait for this thread's stream
+            return a, b
+
+        def sink(t, decon, tmx, rec):
+            outb.copy_(decon, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            api.writetifstack(os.path.join(tdir, f"Decon_{t}.tif"), outb.numpy(), bits=16)
+        tiff_common = dict(common, load_pair=load_tiff)
+        runt = lambda tps: batch.run_sharded(tps, fuse_pair=pipe.fuse_pair, policy=policy(3), sink=sink, overlap=True, **tiff_common)
+        measure("regmode3_tiff", "spimFusionBatch loop, regMode 3, both views READ from 16-bit TIFF stacks and the deconvolved "
+                "16-bit stack WRITTEN inside the timed region (library codec; decode / upload / encode on helper threads): " + base,
+                runt, list(range(world)), {"time_points_in_flight_per_gpu": 1, "tiff_dir": args.batch_tiff_dir})
+        for f in os.listdir(tdir):
+            os.remove(os.path.join(tdir, f))
+    for p in pipes:
+        p.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +327,10 @@ def main():
                     help="time points in flight per GPU in the config-5 figure (host threads, batch.run_sharded(lanes=))")
     ap.add_argument("--batch-time-points-per-gpu", type=int, default=4,
                     help="time points per GPU of the config-5 figure in `extra` (register + joint RL + MIP); 0 = skip")
+    ap.add_argument("--batch-tiff-dir", default="/tmp/mil_bench_tiff",
+                    help="scratch directory of the TIFF-inclusive config-5 figure ('' = skip it)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / collective plumbing only, on the CPU over gloo: no GPU, no measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10, help="RL iterations of the single-thread CPU baseline (~1 s each)")
@@ -128,6 +345,11 @@ def main():
     ap.add_argument("--backend", choices=["auto", "rocfft", "fused"], default="auto",
                     help="transform backend of the RL engine (auto = fused LDS-tiled kernels on power-of-two boxes)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # called directly: start the ranks ourselves, as a child
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -348,50 +570,14 @@ def main():
         }
 
     # ---- supplementary, every N: BASELINE.json configs[4], the time-lapse batch ------------
-    # Each rank registers view B to view A (regMode 3: every time point on its own, reg3d affMethod 6 as the batch
-    # hard-codes), deconvolves the pair jointly (20 iterations) and projects; the XY MIPs are gathered to rank 0 (the
-    # only exchange).  Views resident in HBM -- the TIFF-inclusive form is tools/bench_batch.py --tiff.
+    # Each rank registers view B to view A (reg3d affMethod 6 as the batch hard-codes), deconvolves the pair jointly (20
+    # iterations) and projects; the projections are gathered to rank 0 (the only exchange).
     if args.batch_time_points_per_gpu > 0 and not args.no_extra:
         from microimagelib_amd import batch
-        c2, s2 = np.cos(np.deg2rad(2.0)), np.sin(np.deg2rad(2.0))
-        lin2 = np.array([[c2, 0, -s2], [0, 1, 0], [s2, 0, c2]])
-        centre2 = np.array([SHAPE[2] / 2, SHAPE[1] / 2, SHAPE[0] / 2])
-        known2 = np.concatenate([lin2, (centre2 - lin2 @ centre2 + np.array([3.0, -2.0, 1.0]))[:, None]],
-                                axis=1).astype(np.float32).reshape(12)
-        view_b = mdev.affine_resample(synth_volume(torch, SHAPE, (2.5, 2.5, 6.0), seed=100 + rank), known2, SHAPE)  # same object as view A, other PSF, displaced by 2 deg + shift
-        lanes = max(1, args.batch_lanes)
-        pipes = [batch.FusionPipeline(SHAPE, psf_a, psf_b, iters=20) for _ in range(lanes)]
-        pipe = pipes[0]
-        n_tp = args.batch_time_points_per_gpu * world
-        pol = lambda: batch.RegPolicy(reg_mode=3, reg_choice=2, aff_method=6, ftol=1e-4, it_limit=3000)
-        if lanes > 1:
-            # `lanes` time points in flight per GPU, one host thread each with its own engine: the kernels of one fill the
-            # host round trips between the dependent cost evaluations of the other
-            run = lambda tps: batch.run_sharded(tps, lambda t: (img_a, view_b), [p.fuse_pair for p in pipes], pol(),
-                                                pipe.reg_fn, pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev, lanes=lanes)
-        else:
-            # overlap: the joint RL of time point i runs on a helper thread / its own stream while i + 1 is registered
-            run = lambda tps: batch.run_sharded(tps, lambda t: (img_a, view_b), pipe.fuse_pair, pol(), pipe.reg_fn,
-                                                pipe.check_fn, (SHAPE[1], SHAPE[2]), device=coll_dev, overlap=True)
-        run(list(range(world * lanes)))  # warm-up: one time point per lane and rank
-        fence()
-        tb = time.perf_counter()
-        stack = run(list(range(n_tp)))
-        fence()
-        batch_s = time.perf_counter() - tb
-        if distributed:
-            tt = torch.tensor([batch_s], device=coll_dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            batch_s = float(tt.item())
+        figs = batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, psf_a, psf_b, fence, distributed)
         if rank == 0:
-            result["extra"]["batch_config5"] = {
-                "workload": "spimFusionBatch loop, regMode 3: reg3d (affMethod 6) + joint dual-view RL (20 it) + XY MIP per "
-                            "time point, 512x512x256, views resident in HBM, MIP stack gathered to rank 0",
-                "time_points": n_tp, "time_points_per_s": round(n_tp / batch_s, 3), "elapsed_s": round(batch_s, 3),
-                "time_points_in_flight_per_gpu": lanes, "mip_stack": list(stack.shape)}
-        for p in pipes:
-            p.close()
-        del view_b, pipe, pipes
+            result["extra"]["batch_config5"] = figs.get("regmode3")
+            result["extra"]["batch_config5_by_mode"] = figs
 
     # ---- supplementary: dual view + registration (N = 1 only) ---------------------------
     if world == 1 and not args.no_extra:
@@ -473,11 +659,21 @@ def main():
             t0 = time.perf_counter()
             _, rec = api.decon_singleview(img_h, psf_a_host, iters, out=out_h)
             call_s = time.perf_counter() - t0
+            import ctypes
+            split = (ctypes.c_double * 5)()
+            lib.mil_decon_last_call_split(split)
             calls[str(iters)] = {"iterations": iters, "whole_call_s": round(call_s, 4),
                                  "iterations_per_s_pcie_inclusive": round(iters / call_s, 2),
-                                 "records_prepare_s": round(float(rec[7]), 4), "records_loop_s": round(float(rec[8]), 4)}
+                                 "records_prepare_s": round(float(rec[7]), 4), "records_loop_s": round(float(rec[8]), 4),
+                                 # mil_decon_last_call_split: where the call's seconds went (pageable host buffers)
+                                 "split_s": {"engine_and_buffers": round(split[0], 5), "otfs": round(split[1], 5),
+                                             "h2d_pad_init": round(split[2], 5), "rl_loop": round(split[3], 5),
+                                             "crop_d2h": round(split[4], 5)},
+                                 "h2d_gbs": round(img_h.nbytes / max(split[2], 1e-9) / 1e9, 1),
+                                 "d2h_gbs": round(out_h.nbytes / max(split[4], 1e-9) / 1e9, 1)}
         result["extra"]["libapi_decon_singleview_host_pointers"] = dict(calls[str(args.steps)], by_iterations=calls)
         del img_h, out_h
+        result["extra"]["auxiliary_kernels"] = auxiliary_kernels(torch, mdev, eng, img_a, psf_a)
 
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         img_host = img_a.cpu().numpy()

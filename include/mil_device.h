@@ -35,6 +35,10 @@ int mil_set_texture_weight_bits(int bits);
  * it to the driver (entries a concurrent call is using are left alone).  Returns the number of pool bytes released.
  * MIL_POOL_MB caps the pool per device (default min(6144 MB, 1/16 of the device), least recently freed blocks go first). */
 size_t mil_release_cached_memory(void);
+/* Seconds of this THREAD's last decon_singleview / decon_dualview call (GPU modes), which deconRecords[10] has no slots for:
+ * out5 = {engine + device buffers, OTFs (0 when cached), host->device upload + pad + initial estimate, RL loop,
+ * crop + device->host download}. */
+int mil_decon_last_call_split(double *out5);
 size_t mil_cached_memory_bytes(void);             /* bytes the pool holds right now (all devices) */
 
 /* ---- RL element-wise kernels (in place) ----------------------------------- */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mil_snap_transform_size": (C.c_int, [C.c_int]),
     "mil_release_cached_memory": (C.c_size_t, []),
     "mil_cached_memory_bytes": (C.c_size_t, []),
+    "mil_decon_last_call_split": (C.c_int, [c_double_p]),
     "mil_set_texture_weight_bits": (C.c_int, [C.c_int]),
     "mil_rl_ratio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mil_rl_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),

@@ -17,7 +17,9 @@
 // same sums bit for bit with about half the instructions; DESIGN.md section 4 has the measurements (what bounds these
 // kernels is the texture-address path and VALU issue, not HBM) and the three LDS-staged variants that were built,
 // measured slower and dropped.  Every cost kernel ends in corr_publish (corr_finish.h): one launch per evaluation.
+#include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <chrono>
 
 #include "corr_finish.h"
@@ -167,6 +169,50 @@ __global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restri
     out[(size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z)] = v;
 }
 
+// mip3dgpu's inner pair (src/apifunc.cpp:610-613: affineTransform into the rotated box, then maxprojection along z) in ONE
+// pass: a thread owns an (x, y) of the projection and a segment of z, forms the resampled values exactly as resample_kernel
+// does and keeps their maximum -- the rotated box (670 MB at 512 x 512 x 256, written and read back 36 times per series) never
+// exists.  The maximum is exact and order-independent, so the plane equals the two-kernel result bit for bit.  Segments meet
+// in an atomic max on the integer pattern: the accumulator starts at 0 (maxprojectionkernel :396-418), non-negative floats
+// order like their bit patterns and negative ones stay below 0.
+// Lane layout: LX lanes along x times 64 / LX along z.  A wave's gather then covers an LX x (64 / LX) patch of the (x, z)
+// plane, which a rotation about y maps to a patch of the source's (x, z) plane: 64 x 1 is right while the source planes a wave
+// touches stay few (small angles: 2-3 cache lines per gather, 45 at 45 degrees), 1 x 64 when the march direction has
+// become the source's x axis (near 90 / 270 degrees), 8 x 8 in between.  The z lanes of an (x, y) meet in a wave-level
+// maximum, the z segments of the grid in the atomic.
+template <int LX>
+__global__ __launch_bounds__(kBlockThreads) void resample_mip_kernel(int *__restrict__ out, const float *__restrict__ src,
+                                                                     AffineArgs a, int segments) {
+    constexpr int LZ = 64 / LX;
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * LX + (lane % LX);
+    const int y = blockIdx.y * kTileY + (threadIdx.x >> 6);
+    if (y >= a.ty) return;  // whole wave
+    const int per = (a.tz + segments - 1) / segments;
+    const int z0 = blockIdx.z * per, z1 = min(a.tz, z0 + per);
+    const float ix = (float)x, iy = (float)y;
+    float best = 0.0f;
+    if (x < a.tx) {
+#pragma unroll 4
+        for (int z = z0 + lane / LX; z < z1; z += LZ) {
+            const float iz = (float)z;
+            const float tx = coord(a.m + 0, ix, iy, iz);
+            const float ty = coord(a.m + 4, ix, iy, iz);
+            const float tz = coord(a.m + 8, ix, iy, iz);
+            float v = 0.0f;
+            if (tx >= 0 && ty >= 0 && tz >= 0 && tx < (float)a.sx && ty < (float)a.sy && tz < (float)a.sz)
+                v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
+            best = (best > v) ? best : v;
+        }
+    }
+#pragma unroll
+    for (int off = LX; off < 64; off <<= 1) {
+        const float o = __shfl_xor(best, off, 64);
+        best = (best > o) ? best : o;
+    }
+    if (lane < LX && x < a.tx && best > 0.0f) atomicMax(out + (size_t)x + (size_t)a.tx * y, __float_as_int(best));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -272,6 +318,23 @@ void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims,
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "affine_resample: volume exceeds launch limits");
     if (strict_window) hipLaunchKernelGGL(resample_kernel<true>, grid, dim3(kBlockThreads), 0, s, out, src, a);
     else hipLaunchKernelGGL(resample_kernel<false>, grid, dim3(kBlockThreads), 0, s, out, src, a);
+    MIL_HIP(hipGetLastError());
+}
+
+void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s) {
+    AffineArgs a = make_args(box, src_dims, m);
+    // source rows / planes a wave's gather spreads over, with its 64 lanes along x or along z (see the kernel)
+    const float along_x = 64.f * (fabsf(m.m[4]) + fabsf(m.m[8])), along_z = 64.f * (fabsf(m.m[6]) + fabsf(m.m[10]));
+    const int lx = along_x < 8.f ? 64 : (along_z < 8.f ? 1 : 8);
+    const int lz = 64 / lx;
+    const int segments = std::max(1, std::min(4, a.tz / (lz * 32)));
+    dim3 grid((a.tx + lx - 1) / lx, (a.ty + kTileY - 1) / kTileY, segments);
+    if (grid.y > 65535) throw Error(-1, "resample_mip_z: plane exceeds launch limits");
+    MIL_HIP(hipMemsetAsync(out_plane, 0, (size_t)a.tx * a.ty * sizeof(float), s));
+    int *o = reinterpret_cast<int *>(out_plane);
+    if (lx == 64) hipLaunchKernelGGL(resample_mip_kernel<64>, grid, dim3(kBlockThreads), 0, s, o, src, a, segments);
+    else if (lx == 8) hipLaunchKernelGGL(resample_mip_kernel<8>, grid, dim3(kBlockThreads), 0, s, o, src, a, segments);
+    else hipLaunchKernelGGL(resample_mip_kernel<1>, grid, dim3(kBlockThreads), 0, s, o, src, a, segments);
     MIL_HIP(hipGetLastError());
 }
 

@@ -307,6 +307,15 @@ namespace mil {
 void decon_cache_drop() { decon_cache().drop_idle(); }
 }  // namespace mil
 
+// Where the seconds of this thread's last decon_singleview / decon_dualview call went (mil_decon_last_call_split): the
+// records[10] of the reference's interface have no room for it.  {engine + buffers, OTFs, upload + initial estimate, RL
+// loop, download}; the stream is synchronised at each boundary (four waits of a few microseconds per call).
+static thread_local double g_call_split[5] = {0, 0, 0, 0, 0};
+extern "C" int mil_decon_last_call_split(double *out5) {
+    for (int i = 0; i < 5; ++i) out5[i] = g_call_split[i];
+    return 0;
+}
+
 extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSize, float *h_psf,
                                 unsigned int *psfSize, bool flagConstInitial, int itNumForDecon, int deviceNum,
                                 int gpuMemMode, bool verbose, float *deconRecords, bool flagUnmatch,
@@ -347,10 +356,14 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         DeviceBuffer<float> dA(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
         deconRecords[2] = free_mb();
 
+        const double t_ready = now_s();
         const float2 *dOtf, *dOtfBp;
         view_otfs(cache, eng, dOtf, dOtfBp, dPsf, h_psf, h_psf_bp, flagUnmatch, g);
+        MIL_HIP(hipStreamSynchronize(s));
+        const double t_otf = now_s();
         upload_volume(dA, dStage, h_img, g, s);
         eng.init_single(dA, dE, flagConstInitial);
+        MIL_HIP(hipStreamSynchronize(s));
         const double t_loop = now_s();
         eng.run_single(dE, dA, dOtf, dOtfBp, itNumForDecon);
         eng.synchronize();
@@ -365,6 +378,8 @@ extern "C" int decon_singleview(float *h_decon, float *h_img, unsigned int *imSi
         deconRecords[7] = (float)(t_loop - t_init);
         deconRecords[8] = (float)(t_done - t_loop);
         deconRecords[9] = (float)(t_end - t_start);
+        const double split[5] = {t_ready - t_init, t_otf - t_ready, t_loop - t_otf, t_done - t_loop, t_end - t_done};
+        for (int i = 0; i < 5; ++i) g_call_split[i] = split[i];
         return 0;
     });
 }
@@ -408,13 +423,17 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         DeviceBuffer<float> dA(g.n_box), dB(g.n_box), dE(g.n_box), dPsf(g.n_psf), dStage(g.padded ? g.n_im : 0);
         deconRecords[2] = free_mb();
 
+        const double t_ready = now_s();
         const float2 *dOtf1, *dOtfBp1, *dOtf2, *dOtfBp2;
         view_otfs(cache, eng, dOtf1, dOtfBp1, dPsf, h_psf1, h_psf_bp1, flagUnmatch, g);  // reference :522-534
         view_otfs(cache, eng, dOtf2, dOtfBp2, dPsf, h_psf2, h_psf_bp2, flagUnmatch, g);  // :535-547
+        MIL_HIP(hipStreamSynchronize(s));
+        const double t_otf = now_s();
         upload_volume(dA, dStage, h_img1, g, s);
         if (g.padded) MIL_HIP(hipStreamSynchronize(s));  // dStage is reused for the second view
         upload_volume(dB, dStage, h_img2, g, s);
         eng.init_dual(dA, dB, dE, flagConstInitial);
+        MIL_HIP(hipStreamSynchronize(s));
         const double t_loop = now_s();
         eng.run_dual(dE, dA, dB, dOtf1, dOtf2, dOtfBp1, dOtfBp2, itNumForDecon);
         eng.synchronize();
@@ -428,6 +447,8 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
         deconRecords[7] = (float)(t_loop - t_init);
         deconRecords[8] = (float)(t_done - t_loop);
         deconRecords[9] = (float)(t_end - t_start);
+        const double split[5] = {t_ready - t_init, t_otf - t_ready, t_loop - t_otf, t_done - t_loop, t_end - t_done};
+        for (int i = 0; i < 5; ++i) g_call_split[i] = split[i];
         if (verbose) printf("\t... deconvolution done !!! \n");
         return 0;
     });

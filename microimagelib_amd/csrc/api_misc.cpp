@@ -1,6 +1,7 @@
 // libapi.h helpers around the hot path: device query, maximum-intensity projections,
 // resize / rotate / size alignment.  Reference: src/apifunc.cpp:328-644.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -124,22 +125,30 @@ extern "C" int mp2dgpu(float *h_MP, unsigned int *sizeMP, float *h_img, unsigned
 
 namespace {
 
-// One rotation series: resample into the rotated box, project along z, keep the plane -- in device memory (d_out, one plane
-// per angle) or, for the host-pointer entry points, copied out plane by plane like the reference (src/apifunc.cpp:610-618).
+// One rotation series: resample into the rotated box and project along z -- one fused pass per angle (k::resample_mip_z;
+// MIL_MIP3D_FUSED=0 runs the reference's two kernels, affineTransform then maxprojection, for comparison) -- and keep the
+// plane: in device memory (d_out, one plane per angle) or, for the host-pointer entry points, copied out plane by plane like
+// the reference (src/apifunc.cpp:610-618).
 void mip_series(float *h_out, float *d_out, const float *d_img, Dims img, Dims rot_box, int axis, long long project_num,
                 float project_step, hipStream_t s) {
     const size_t plane = (size_t)rot_box.nx * rot_box.ny;
-    DeviceBuffer<float> d_rot((size_t)rot_box.count()), d_proj(d_out ? 0 : plane);
+    const char *e = getenv("MIL_MIP3D_FUSED");
+    const bool fused = !(e && e[0] == '0');
+    DeviceBuffer<float> d_rot(fused ? 0 : (size_t)rot_box.count()), d_proj(d_out ? 0 : plane);
     for (long long i = 0; i < project_num; ++i) {
         const float angle = project_step * (float)(int)i;
         k::Affine12 m;
         rot2matrix(m.m, angle, img.nx, img.ny, img.nz, axis);
-        k::affine_resample(d_rot.get(), d_img, rot_box, img, m, s);
         float *proj = d_out ? d_out + plane * (size_t)i : d_proj.get();
-        k::max_projection(proj, d_rot.get(), rot_box, 1, s);
+        if (fused) {
+            k::resample_mip_z(proj, d_img, rot_box, img, m, s);
+        } else {
+            k::affine_resample(d_rot.get(), d_img, rot_box, img, m, s);
+            k::max_projection(proj, d_rot.get(), rot_box, 1, s);
+        }
         if (h_out) MIL_HIP(hipMemcpyAsync(h_out + plane * (size_t)i, proj, plane * sizeof(float), hipMemcpyDeviceToHost, s));
     }
-    MIL_HIP(hipStreamSynchronize(s));  // d_rot is freed on return
+    MIL_HIP(hipStreamSynchronize(s));  // the scratch buffers are freed on return
 }
 
 // rotated box of mip3dgpu (src/apifunc.cpp:582-590): the rotation axis keeps its extent, the other two become the diagonal

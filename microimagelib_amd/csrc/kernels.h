@@ -84,6 +84,9 @@ void set_texture_weight_bits(int bits);  // 0 | 8 | anything else: back to the e
 // strict_window: lower bound 0 < t instead of 0 <= t (the reference's 2-D transform kernel).
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m,
                      hipStream_t s, bool strict_window = false);
+// affine_resample into `box` followed by the maximum projection along z, fused: out_plane[box.ny][box.nx] (mip3dgpu's
+// inner pair, src/apifunc.cpp:610-613); same bits as the two kernels one after the other
+void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s);
 constexpr int kCorrCounters = 64;  // first-level completion counters of a cost kernel (+ 1 top-level)
 struct CorrTail {  // what the last workgroup of a cost kernel needs (corr_finish.h)
     double *partials;   // [2][nblocks]

@@ -179,6 +179,22 @@ def test_mip3d_matches_oracle(api):
             assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), f"axis {axis} angle {i}"
 
 
+def test_fused_mip3d_equals_the_two_kernel_sequence(api, monkeypatch):
+    """mip3dgpu runs resample + z projection as ONE kernel per angle (the rotated box never exists); MIL_MIP3D_FUSED=0 runs the
+    reference's sequence affineTransform -> maxprojection (src/apifunc.cpp:610-613).  Same bits, also with negative voxels
+    (the projection's accumulator starts at 0) and with more z steps than one segment of the fused kernel covers."""
+    rng = np.random.default_rng(5)
+    vol = (do.blob_volume((40, 70, 90), n_blobs=25, seed=9) - f32(120.0)).astype(np.float32)  # background below zero
+    vol += rng.standard_normal(vol.shape).astype(np.float32)
+    for axis in (1, 2):
+        monkeypatch.setenv("MIL_MIP3D_FUSED", "0")
+        want = api.mip3dgpu(vol, axis, 9)
+        monkeypatch.delenv("MIL_MIP3D_FUSED")
+        got = api.mip3dgpu(vol, axis, 9)
+        assert want.min() == 0.0 and want.max() > 0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"axis {axis}"
+
+
 # ---------------------------------------------------------------- regChoice 4: 2-D MIP shift search
 def _shifted_pair(shape=(24, 40, 48), shift=(3.0, -2.0, 1.6)):
     tgt = do.blob_volume(shape, n_blobs=15, seed=3)
