@@ -1,6 +1,7 @@
 """Generates the committed golden vectors under tests/golden/ (run once, here, on CPU):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py          (everything)
+    python tests/golden/make_golden.py traj     (only reg3d_traj.npz, from the committed reg3d.npz)
 
 Sources of truth
   * powell_ref.npz      -- produced by oracle/_ref/libpowell_ref.so, i.e. the reference's own
@@ -170,10 +171,46 @@ def registration_case():
     save("reg3d.npz", tgt=tgt, src=src, known=known, **out)
 
 
+def registration_trajectories():
+    """reg3d_traj.npz: EVERY matrix reg3d_affine1 (src/api_subfunc.cu:2889-2961) evaluates, with the cost it saw, for the cases of
+    reg3d.npz -- affMethod 2, 5, 6, 7 from the identity, and the two input-matrix paths (affMethod 2: pre-transform, register
+    from the identity, compose; affMethod 5: the matrix is the start point) -- driven by the COMPILED reference powell().  The
+    -m gpu tests demand the same evaluations bit for bit (mil_reg3d_trace_*), not just an equally good optimum."""
+    g = np.load(os.path.join(HERE, "reg3d.npz"))
+    tgt, src = g["tgt"], g["src"]
+    if not po.ref_available():
+        raise SystemExit("oracle/_ref/libpowell_ref.so missing: run `make -C oracle ref` first")
+    start = ro.dof9tomatrix(np.array([0, -1.0, 0.5, -0.5, 0, 0, 0, 1, 1, 1], dtype=f32), 3)
+    real_corrfunc = ro.corrfunc
+    out = {"start": start}
+    cases = [(f"m{m}", m, False, None) for m in (2, 5, 6, 7)] + [("in2", 2, True, start), ("in5", 5, True, start)]
+    for key, method, flag, tmx0 in cases:
+        trace = []
+
+        def tracing(target, sd_t, s, m):
+            c = real_corrfunc(target, sd_t, s, m)
+            trace.append(np.concatenate([np.asarray(m, dtype=f32), [f32(-c)]]).astype(f32))
+            return c
+        ro.corrfunc = tracing
+        try:
+            reg, tmx, rec = ro.Reg3dAffine(po.ref_powell).run(tgt, src, method, flag_tmx=flag, i_tmx=tmx0, ftol=1e-4, it_limit=3000)
+        finally:
+            ro.corrfunc = real_corrfunc
+        if not flag:  # the same run as reg3d.npz holds
+            assert np.array_equal(rec, g[f"m{method}_records"]) and np.array_equal(tmx, g[f"m{method}_tmx"])
+        out[key + "_trace"], out[key + "_tmx"], out[key + "_records"], out[key + "_reg"] = np.stack(trace), tmx, rec, reg
+        print(key, len(trace), "evaluations, ZNCC", rec[1], "->", rec[3])
+    save("reg3d_traj.npz", **out)
+
+
 if __name__ == "__main__":
+    if "traj" in sys.argv[1:]:
+        registration_trajectories()
+        raise SystemExit(0)
     decon_cases()
     geometry_cases()
     affine_cases()
     matrix_tables()
     powell_ref()
     registration_case()
+    registration_trajectories()

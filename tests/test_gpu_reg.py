@@ -90,35 +90,48 @@ def test_reg3d_self_registration_stays_at_identity(api):
     assert api.checkmatrix(tmx, 40, 32, 24)
 
 
+def _assert_same_registration(api, dev, g, key, **call):
+    """reg3d must make the oracle's evaluations one by one -- same matrices bit for bit, same costs to 1e-6, same count -- and
+    hand back the same matrix, records and resampled volume (tests/golden/reg3d_traj.npz: the oracle's driver with the
+    reference's compiled powell(), make_golden.py traj)."""
+    want = g[key + "_trace"]
+    dev.reg3d_trace_begin(len(want) + 16)
+    try:
+        out, tmx, rec = api.reg3d(g["tgt"], g["src"], ftol=1e-4, it_limit=3000, **call)
+        got, seen = dev.reg3d_trace_read(len(want) + 16)
+    finally:
+        dev.reg3d_trace_begin(0)
+    w_rec = g[key + "_records"]
+    assert seen == len(want), (key, seen, len(want))
+    same = np.all(got[:, :12].view(np.uint32) == want[:, :12].view(np.uint32), axis=1)
+    assert same.all(), f"{key}: first differing evaluation {int(np.argmin(same))} of {len(want)}"
+    assert np.max(np.abs(got[:, 12].astype(np.float64) - want[:, 12])) <= 1e-6
+    assert rec[5] == w_rec[5] == len(want) - 1  # evaluations after the initial one (src/api_subfunc.cu:2888)
+    for i in (1, 2, 3):
+        assert abs(float(rec[i]) - float(w_rec[i])) <= 1e-6, (key, i, rec[i], w_rec[i])
+    assert np.array_equal(tmx.view(np.uint32), g[key + "_tmx"].view(np.uint32)), key
+    assert np.array_equal(out.view(np.uint32), g[key + "_reg"].view(np.uint32)), key
+
+
 @pytest.mark.parametrize("method", [2, 5, 6, 7])
-def test_reg3d_golden(api, method):
-    """End to end against the oracle cost driven by the COMPILED REFERENCE Powell.  The cost
-    kernel is bit-exact per voxel and the reductions are float64, so the trajectories normally
-    coincide; the assertion tolerates a late divergence (one float32 rounding flip)."""
-    g = np.load(os.path.join(GOLD, "reg3d.npz"))
-    out, tmx, rec = api.reg3d(g["tgt"], g["src"], aff_method=method, ftol=1e-4, it_limit=3000)
-    want_rec = g[f"m{method}_records"]
-    assert abs(rec[1] - want_rec[1]) < 1e-6          # initial ZNCC
-    assert rec[3] >= want_rec[3] - 5e-3              # final ZNCC at least as good
-    assert abs(rec[2] - want_rec[2]) < 5e-3          # intermediate ZNCC (methods 6, 7)
-    same_path = rec[5] == want_rec[5]
-    if same_path:
-        assert np.max(np.abs(tmx - g[f"m{method}_tmx"])) < 1e-5
-        assert np.max(np.abs(out - g[f"m{method}_reg"])) <= 1e-4 * np.max(np.abs(g[f"m{method}_reg"]))
-    print(f"method {method}: evals {rec[5]:.0f} (oracle {want_rec[5]:.0f}), same path: {same_path}")
+def test_reg3d_golden(api, dev, method):
+    """End to end against the oracle cost driven by the COMPILED REFERENCE Powell, every affMethod schedule
+    (src/api_subfunc.cu:2889-2957): translation -> rigid -> 12 DOF (2), direct 12 DOF (5), and the cascades 6 and 7."""
+    g = np.load(os.path.join(GOLD, "reg3d_traj.npz"))
+    old = np.load(os.path.join(GOLD, "reg3d.npz"))
+    assert np.array_equal(g[f"m{method}_records"], old[f"m{method}_records"])  # the run reg3d.npz was made from
+    _assert_same_registration(api, dev, dict(g, tgt=old["tgt"], src=old["src"]), f"m{method}", aff_method=method)
 
 
-def test_reg3d_with_input_matrix(api, dev):
-    """flagTmx with affMethod != 5: pre-transform, register from identity, compose (reference :2958-2961)."""
-    g = np.load(os.path.join(GOLD, "reg3d.npz"))
-    start = ro.dof9tomatrix(np.array([0, -1.0, 0.5, -0.5, 0, 0, 0, 1, 1, 1], dtype=f32), 3)
-    powell = po.ref_powell if po.ref_available() else po.powell
-    want_reg, want_tmx, want_rec = ro.Reg3dAffine(powell).run(g["tgt"], g["src"], 2, flag_tmx=True, i_tmx=start)
-    out, tmx, rec = api.reg3d(g["tgt"], g["src"], i_tmx=start, aff_method=2, input_tmx=True)
-    assert abs(rec[1] - want_rec[1]) < 1e-6
-    assert rec[3] >= want_rec[3] - 5e-3
-    if rec[5] == want_rec[5]:
-        assert np.max(np.abs(tmx - want_tmx)) < 1e-5
+@pytest.mark.parametrize("key,method", [("in2", 2), ("in5", 5)])
+def test_reg3d_with_input_matrix(api, dev, key, method):
+    """flagTmx: with affMethod != 5 the source is first resampled by the input matrix, registration runs from the identity
+    and the result is composed as iTmx . M (src/api_subfunc.cu:2958-2961); with affMethod 5 the matrix is the start point
+    (:2818-2821).  Same evaluations as the oracle, one by one."""
+    g = np.load(os.path.join(GOLD, "reg3d_traj.npz"))
+    old = np.load(os.path.join(GOLD, "reg3d.npz"))
+    _assert_same_registration(api, dev, dict(g, tgt=old["tgt"], src=old["src"]), key, aff_method=method, i_tmx=g["start"],
+                              input_tmx=True)
 
 
 def test_reg3d_different_source_size(api):
