@@ -24,6 +24,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -274,7 +275,10 @@ int main(int argc, char **argv) {
         cli::Volume a_res, b_rot_own, b_res;
         cli::Volume *a = nullptr, *b = nullptr;
     };
-    std::atomic<bool> failed{false};
+    // index of the first time point that failed (INT_MAX: none).  The batch stops WHERE THE REFERENCE STOPS: time points before
+    // it are completed by whichever worker owns them, time points after it are not started (one in flight is abandoned before
+    // it writes anything).
+    std::atomic<int> fail_at{INT_MAX};
     auto preprocess = [&](Prepared &p, int dev) -> bool {
         cli::Volume &a_in = p.in.first, &b_in = p.in.second;
         if (a_in.size[0] != in1[0] || a_in.size[1] != in1[1] || a_in.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); return false; }
@@ -378,15 +382,12 @@ int main(int argc, char **argv) {
         size_t ahead_i = 0;
         std::future<void> behind;
         auto stop = [&](int index) {  // a failed worker must not leave the others waiting for the chain or the log
-            failed = true;
-            {
-                std::lock_guard<std::mutex> lock(chain.mu);
-                chain.next = (int)points.size() + 1;
-            }
+            int seen = fail_at.load();
+            while (index < seen && !fail_at.compare_exchange_weak(seen, index)) {}
+            { std::lock_guard<std::mutex> lock(chain.mu); }  // a waiter is either before its predicate test or asleep
             chain.cv.notify_all();
-            (void)index;
         };
-        for (size_t i = (size_t)w; i < points.size() && !failed; i += (size_t)n_workers) {
+        for (size_t i = (size_t)w; i < points.size() && (int)i < fail_at.load(); i += (size_t)n_workers) {
             const int n = points[i];
             Lines out;
             out("\n*** Image time point number: %d \n", n);
@@ -394,7 +395,24 @@ int main(int argc, char **argv) {
 
             // ---- stacks: read ahead by this worker's previous time point, or read now
             Prepared p;
-            p.in = (ahead.valid() && ahead_i == i) ? ahead.get() : load_pair(n);
+            if (ahead.valid() && ahead_i == i) {
+                p.in = ahead.get();
+            } else {
+                // A missing stack ends the batch HERE, in order: the library's readers exit() the process on an unreadable file
+                // (like the reference's), which from one of several worker threads would cut the other workers' deconvolutions
+                // and half-written stacks off and drop the buffered log.  Checked first, the failure goes through stop(): the
+                // others finish their time point, the log is flushed, main returns 1.
+                const std::string fa = name_of(dir1, base1, n), fb = name_of(dir2, base2, n);
+                const bool have_a = fexists(const_cast<char *>(fa.c_str())), have_b = fexists(const_cast<char *>(fb.c_str()));
+                if (!have_a || !have_b) {
+                    out("\t... input stack %s does not exist, processing stopped !!!\n", (have_a ? fb : fa).c_str());
+                    fprintf(stderr, "spimFusionBatch: %s does not exist\n", (have_a ? fb : fa).c_str());
+                    log.publish((int)i, std::move(out.text));
+                    stop((int)i);
+                    break;
+                }
+                p.in = load_pair(n);
+            }
             {   // this worker's next time point: only when both files are there -- a missing file must stop the batch where
                 // the reference stops it, after the earlier time points' results are written
                 const size_t ni = i + (size_t)n_workers;
@@ -415,12 +433,12 @@ int main(int argc, char **argv) {
             case 0: reg_status = run_reg(st, p, b_reg, reg_records, 0, st.have_itmx, dev); break;
             case 2: {
                 std::unique_lock<std::mutex> lock(chain.mu);
-                chain.cv.wait(lock, [&] { return chain.next >= (int)i; });
-                if (chain.next != (int)i) break;  // another worker failed
+                chain.cv.wait(lock, [&] { return fail_at.load() < (int)i || chain.next >= (int)i; });
+                if (fail_at.load() < (int)i || chain.next != (int)i) break;  // an earlier time point failed: the chain ends there
                 lock.unlock();  // the state is this worker's alone until it advances `next`
                 if (i == 0) {
                     reg_status = ladder(st, p, b_reg, reg_records, reg_choice, dev, out);
-                    std::memcpy(chain.weighted, st.tmx, sizeof st.tmx);
+                    if (reg_status == 0) std::memcpy(chain.weighted, st.tmx, sizeof st.tmx);
                 } else {  // start from the running average, fall back to the previous matrix (:786-808)
                     std::memcpy(st.tmx, chain.weighted, sizeof st.tmx);
                     reg_status = run_reg(st, p, b_reg, reg_records, 2, true, dev);
@@ -429,8 +447,10 @@ int main(int argc, char **argv) {
                         std::memcpy(st.tmx, chain.previous, sizeof st.tmx);
                         reg_status = run_reg(st, p, b_reg, reg_records, 0, true, dev);
                     }
-                    for (int j = 0; j < 12; ++j) chain.weighted[j] = (float)(0.8 * chain.weighted[j] + 0.2 * st.tmx[j]);  // double arithmetic, :805-807
+                    if (reg_status == 0)
+                        for (int j = 0; j < 12; ++j) chain.weighted[j] = (float)(0.8 * chain.weighted[j] + 0.2 * st.tmx[j]);  // double arithmetic, :805-807
                 }
+                if (reg_status != 0) break;  // the chain does NOT advance from a failed registration: stop() below wakes the others
                 std::memcpy(chain.previous, st.tmx, sizeof st.tmx);
                 lock.lock();
                 chain.next = (int)i + 1;
@@ -446,7 +466,7 @@ int main(int argc, char **argv) {
                 stop((int)i);
                 break;
             }
-            if (failed) break;
+            if (fail_at.load() < (int)i) break;  // an earlier time point failed while this one registered: write nothing
             out("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
                 reg_records[1], reg_records[3], reg_records[7]);
             const std::string ns = std::to_string(n);
@@ -514,7 +534,7 @@ int main(int argc, char **argv) {
         for (int w = 0; w < (int)devices.size(); ++w) threads.emplace_back(worker, w);
         for (auto &t : threads) t.join();
     }
-    if (failed) { log.flush(); return 1; }
+    if (fail_at.load() != INT_MAX) { log.flush(); return 1; }
     log.direct("\n=== Batch processing completed, whole time cost: %2.3f s\n", sec(t_batch, std::chrono::steady_clock::now()));
     return 0;
 }

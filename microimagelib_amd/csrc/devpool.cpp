@@ -32,6 +32,23 @@ struct Cached {
     int device;
 };
 
+// Runs f with `device` current, restoring the caller's device afterwards.
+template <class F>
+void on_device(int device, F &&f) noexcept {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    f();
+    if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+}
+
+// Blocks leaving the pool: collected under the lock, given to the driver AFTER it is released -- hipFree synchronises the
+// device, and every other thread's pool_alloc / pool_free would wait behind it (lanes, several workers on one device).
+using Doomed = std::vector<void *>;
+void free_doomed(const Doomed &d) noexcept {
+    for (void *p : d) (void)hipFree(p);
+}
+
 struct Pool {
     std::mutex mu;
     std::list<Cached> lru;  // front = freed longest ago
@@ -51,15 +68,15 @@ struct Pool {
         } else {
             cap = (size_t)6144 << 20;
             size_t free_b = 0, total_b = 0;
-            int cur = 0;
-            if (hipGetDevice(&cur) == hipSuccess && cur == device && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-                total_b / 16 < cap)
-                cap = total_b / 16;
+            bool ok = false;  // the size of THAT device, whichever one the calling thread has current
+            on_device(device, [&] { ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess; });
+            if (!ok) return cap;  // not cached: asked again next time
+            if (total_b / 16 < cap) cap = total_b / 16;
         }
         cap_bytes[device] = cap;
         return cap;
     }
-    void drop_locked(std::list<Cached>::iterator it) {
+    void drop_locked(std::list<Cached>::iterator it, Doomed &doomed) {
         auto &vec = free_blocks[{it->device, it->bytes}];
         for (size_t i = 0; i < vec.size(); ++i)
             if (vec[i] == it) {
@@ -67,11 +84,11 @@ struct Pool {
                 break;
             }
         cached_bytes[it->device] -= it->bytes;
-        (void)hipFree(it->p);
+        doomed.push_back(it->p);
         lru.erase(it);
     }
-    void release_all_locked() {
-        for (auto &c : lru) (void)hipFree(c.p);
+    void release_all_locked(Doomed &doomed) {
+        for (auto &c : lru) doomed.push_back(c.p);
         lru.clear();
         free_blocks.clear();
         cached_bytes.clear();
@@ -88,16 +105,6 @@ size_t round_up(size_t bytes) {
     return (bytes + g - 1) / g * g;
 }
 
-// Runs f with `device` current, restoring the caller's device afterwards.
-template <class F>
-void on_device(int device, F &&f) noexcept {
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    if (cur != device) (void)hipSetDevice(device);
-    f();
-    if (cur != device && cur >= 0) (void)hipSetDevice(cur);
-}
-
 int device_of(void *p) {
     Pool &pl = pool();
     std::lock_guard<std::mutex> lock(pl.mu);
@@ -107,28 +114,32 @@ int device_of(void *p) {
 
 void give_back(void *p) noexcept {
     Pool &pl = pool();
-    std::lock_guard<std::mutex> lock(pl.mu);
-    auto it = pl.live.find(p);
-    if (it == pl.live.end()) {
-        (void)hipFree(p);
-        return;
+    Doomed doomed;
+    {
+        std::lock_guard<std::mutex> lock(pl.mu);
+        auto it = pl.live.find(p);
+        if (it == pl.live.end()) {
+            doomed.push_back(p);
+        } else {
+            const Block b = it->second;
+            pl.live.erase(it);
+            const size_t cap = pl.cap_of(b.device);
+            if (b.bytes > cap) {
+                doomed.push_back(p);
+            } else {
+                // make room: least recently freed blocks of this device first
+                for (auto c = pl.lru.begin(); c != pl.lru.end() && pl.cached_bytes[b.device] + b.bytes > cap;) {
+                    auto next = std::next(c);
+                    if (c->device == b.device) pl.drop_locked(c, doomed);
+                    c = next;
+                }
+                pl.lru.push_back(Cached{p, b.bytes, b.device});
+                pl.free_blocks[{b.device, b.bytes}].push_back(std::prev(pl.lru.end()));
+                pl.cached_bytes[b.device] += b.bytes;
+            }
+        }
     }
-    const Block b = it->second;
-    pl.live.erase(it);
-    const size_t cap = pl.cap_of(b.device);
-    if (b.bytes > cap) {
-        (void)hipFree(p);
-        return;
-    }
-    // make room: least recently freed blocks of this device first
-    for (auto c = pl.lru.begin(); c != pl.lru.end() && pl.cached_bytes[b.device] + b.bytes > cap;) {
-        auto next = std::next(c);
-        if (c->device == b.device) pl.drop_locked(c);
-        c = next;
-    }
-    pl.lru.push_back(Cached{p, b.bytes, b.device});
-    pl.free_blocks[{b.device, b.bytes}].push_back(std::prev(pl.lru.end()));
-    pl.cached_bytes[b.device] += b.bytes;
+    free_doomed(doomed);
 }
 
 }  // namespace
@@ -139,25 +150,33 @@ void *pool_alloc(size_t bytes) {
     const size_t sz = round_up(bytes);
     int dev = 0;
     MIL_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(pl.mu);
-    auto it = pl.free_blocks.find({dev, sz});
-    if (it != pl.free_blocks.end() && !it->second.empty()) {
-        auto c = it->second.back();
-        it->second.pop_back();
-        void *p = c->p;
-        pl.cached_bytes[dev] -= sz;
-        pl.lru.erase(c);
-        pl.live[p] = Block{sz, dev};
-        return p;
+    {
+        std::lock_guard<std::mutex> lock(pl.mu);
+        auto it = pl.free_blocks.find({dev, sz});
+        if (it != pl.free_blocks.end() && !it->second.empty()) {
+            auto c = it->second.back();
+            it->second.pop_back();
+            void *p = c->p;
+            pl.cached_bytes[dev] -= sz;
+            pl.lru.erase(c);
+            pl.live[p] = Block{sz, dev};
+            return p;
+        }
     }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, sz);
+    hipError_t e = hipMalloc(&p, sz);  // outside the lock: the driver call may take milliseconds
     if (e != hipSuccess) {  // give the cache back and try once more
         (void)hipGetLastError();
-        pl.release_all_locked();
+        Doomed doomed;
+        {
+            std::lock_guard<std::mutex> lock(pl.mu);
+            pl.release_all_locked(doomed);
+        }
+        free_doomed(doomed);
         e = hipMalloc(&p, sz);
     }
     check_hip(e, "hipMalloc", __FILE__, __LINE__);
+    std::lock_guard<std::mutex> lock(pl.mu);
     pl.live[p] = Block{sz, dev};
     return p;
 }
@@ -180,10 +199,14 @@ void pool_free_after(void *p, hipStream_t s) noexcept {
 
 size_t pool_release_all() {
     Pool &pl = pool();
-    std::lock_guard<std::mutex> lock(pl.mu);
+    Doomed doomed;
     size_t n = 0;
-    for (auto &kv : pl.cached_bytes) n += kv.second;
-    pl.release_all_locked();
+    {
+        std::lock_guard<std::mutex> lock(pl.mu);
+        for (auto &kv : pl.cached_bytes) n += kv.second;
+        pl.release_all_locked(doomed);
+    }
+    free_doomed(doomed);
     return n;
 }
 

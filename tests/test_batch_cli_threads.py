@@ -131,3 +131,49 @@ def test_a_failed_library_call_stops_the_batch(tmp_path, tool, devices):
     assert len(written) < 6  # the failed time point (and whatever would have followed it on that worker) has no matrix file
     log = open(out / "ProcessingLog.txt").read()
     assert "registration failed" in log and "Batch processing completed" not in log
+
+
+@pytest.mark.parametrize("devices", ["0", "0,1,2"])
+def test_a_missing_stack_stops_the_batch_in_order(tmp_path, tool, devices):
+    """A time point whose input stack is missing: the library's TIFF readers exit() the process like the reference's, which
+    from one of several worker threads would cut the other workers' time points off and drop the buffered log.  The worker
+    checks first and routes the failure through the batch's stop path: exit status 1, every earlier time point complete
+    (stack, matrix, projection -- files whole, not truncated), log flushed in order up to the failure."""
+    n_points = 7
+    _series(tmp_path, n_points)
+    os.remove(tmp_path / "SPIMB" / "SPIMB_4.tif")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    out = tmp_path / "out_missing"
+    r = subprocess.run([tool] + _args(tmp_path, out, 3, devices, n_points), capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 1, (r.returncode, r.stdout[-1500:], r.stderr[-2000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert "SPIMB_4.tif does not exist" in r.stderr
+    tree = _tree(out)
+    full = tmp_path / "out_full"  # what a complete time point looks like
+    _write_tiff32(tmp_path / "SPIMB" / "SPIMB_4.tif", np.random.default_rng(1).uniform(10, 500, (6, 10, 12)))
+    r2 = subprocess.run([tool] + _args(tmp_path, full, 3, "0", n_points), capture_output=True, text=True, timeout=600, env=env)
+    assert r2.returncode == 0
+    want = _tree(full)
+    for t in range(4):  # time points before the missing one: present and byte-identical with the complete run
+        for name in (os.path.join("Decon", f"Decon_{t}.tif"), os.path.join("TMX", f"Matrix_{t}.tmx")):
+            assert tree.get(name) == want[name], (devices, name)
+    assert os.path.join("TMX", "Matrix_4.tmx") not in tree
+    for name, data in tree.items():  # nothing half-written under a valid name
+        assert data == want[name], name
+    log = open(out / "ProcessingLog.txt").read()
+    assert "does not exist, processing stopped" in log and "Batch processing completed" not in log
+    seen = [int(line.split(":")[1]) for line in log.splitlines() if line.startswith("*** Image time point number")]
+    assert seen == sorted(seen) and seen[:5] == [0, 1, 2, 3, 4]
+
+
+def test_a_failed_chained_registration_does_not_advance_the_chain(tmp_path, tool):
+    """regMode 2, three workers: the registration of time point 2 fails.  Its successors must NOT register from the state it
+    left behind (the stop sentinel used to be overwritten by `next = i + 1`): no matrix file for time point 2 or later."""
+    _series(tmp_path, 7)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", MIL_STUB_FAIL_REG_CALL="3")
+    out = tmp_path / "out_chain_fail"
+    r = subprocess.run([tool] + _args(tmp_path, out, 2, "0,1,2", 7), capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    mats = sorted(n for n in _tree(out) if n.startswith("TMX"))
+    assert mats == [os.path.join("TMX", "Matrix_0.tmx"), os.path.join("TMX", "Matrix_1.tmx")], mats
