@@ -134,8 +134,13 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
  * chooses per matrix.  Kernels 0-5 return the same bits; kernel 6 sums the same voxel values in another order (equal to
  * ~1e-15 relative). */
 int mil_corr_padded_force_kernel(int kernel);
-/* host logic only (no GPU needed): which of the three the per-matrix choice takes for m12 */
+/* host logic only (no GPU needed): the LAYOUT the per-matrix choice takes for m12 -- 0 plain + plane reuse, 1 row pairs,
+ * 2 row pairs + plane reuse (the one-voxel kernels; what runs when the target width is not a multiple of 128) */
 int mil_corr_padded_pick_kernel(const float *m12);
+/* the same choice as a KERNEL number (mil_corr_padded_force_kernel's numbering): wide != 0 for target widths that are
+ * multiples of 128 -- 3 / 5 (two voxels per lane), 1 (row pairs, both planes gathered: one voxel per lane also there), or
+ * 6 (march along y) where the re-gather rate along y is below 0.08 AND below half the rate along z; wide == 0: as above */
+int mil_corr_padded_pick_kernel2(const float *m12, int wide);
 /* cost-kernel launches of this thread's last mil_reg3d_affine (records[5] counts evaluations like the reference; repeats of
  * a point just visited are answered from the last results, same value, no launch) */
 int mil_reg3d_last_cost_launches(void);

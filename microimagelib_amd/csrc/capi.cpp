@@ -282,6 +282,11 @@ int mil_corr_padded_pick_kernel(const float *m12) {
     std::memcpy(m.m, m12, sizeof m.m);
     return k::corr_padded_pick_kernel(m);
 }
+int mil_corr_padded_pick_kernel2(const float *m12, int wide) {
+    k::Affine12 m;
+    std::memcpy(m.m, m12, sizeof m.m);
+    return k::corr_padded_pick_kernel(m, wide != 0);
+}
 int mil_corr_padded_force_kernel(int kernel) {
     k::corr_padded_force_kernel(kernel);
     return 0;

@@ -321,7 +321,9 @@ __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__r
 //     compares, selects or offset substitution.
 // Each voxel keeps its own float64 accumulators, and the sums are combined in the order the one-voxel-per-lane kernels
 // use -- a wave here covers two of their waves, a workgroup two of their workgroups, published separately
-// (corr_publish_as) -- so every cost kernel returns the same bits.
+// (corr_publish_as) -- so the z-marching kernels (0-5) all return the same bits.  Kernel 6 (MARCHY below) adds the same
+// float32 voxel values in another order: equal to ~1e-15 relative, and since the choice is made per matrix, ONE Powell
+// trajectory mixes the two summation orders (the full-size trajectory test still sees the oracle's matrices bit for bit).
 //
 // MARCHY (plain layout with reuse only): the lane marches along y inside ONE target plane instead of along z -- tiles of
 // 128 (x) x 16 (y steps) x 4 (z: the waves) -- and reuses source ROWS instead of planes.  Which axis to march along decides
@@ -756,8 +758,9 @@ int magic_origin(int origin4, int row4, int plane4, int shift) {
 
 void corr_padded_force_kernel(int kernel) { g_forced_kernel = kernel; }
 
-int corr_padded_pick_kernel(const Affine12 &m) { return pick_layout(m.m, true); }
-int corr_padded_pick_kernel_wide(const Affine12 &m) { return pick_kernel(m.m, true, true); }
+int corr_padded_pick_kernel(const Affine12 &m, bool wide) {
+    return wide ? pick_kernel(m.m, true, true) : pick_layout(m.m, true);
+}
 
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t, const Affine12 &m, CorrWorkspace &ws,
                             hipStream_t s) {

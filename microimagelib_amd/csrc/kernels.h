@@ -138,7 +138,7 @@ struct PaddedSource {
 // per lane | -1 (default) per matrix
 void corr_padded_force_kernel(int kernel);
 // host logic only: the kernel the per-matrix choice takes when both layouts are held (0 / 1 / 2 as above)
-int corr_padded_pick_kernel(const Affine12 &m);
+int corr_padded_pick_kernel(const Affine12 &m, bool wide = false);
 void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t_dims, const Affine12 &m,
                             CorrWorkspace &ws, hipStream_t s);
 void corr_sums_padded_sync(const float *target, const PaddedSource &src, Dims t_dims, const Affine12 &m,

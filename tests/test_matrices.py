@@ -126,3 +126,21 @@ def test_cost_kernel_choice_per_matrix(lib):
     assert pick(rot_y(5.0)) == 2 and pick(rot_y(10.0)) == 2
     assert pick(rot_y(20.0)) == 1 and pick(rot_y(45.0)) == 1
     assert pick(np.full(12, np.nan, dtype=f32)) == 0   # NaN never satisfies a threshold; any kernel rejects every voxel
+
+    # the kernel that really runs on a target whose width is a multiple of 128 (two voxels per lane; csrc/corr_padded.hip
+    # pick_kernel): kernel 6 marches along y where THAT axis re-gathers rarely -- rate below 0.08 and below half of z's
+    def pick2(m, wide=1):
+        return lib.mil_corr_padded_pick_kernel2(fp(np.ascontiguousarray(m, dtype=f32)), wide)
+
+    def rot_x(deg):
+        c, s = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
+        return np.array([1, 0, 0, 2.0, 0, c, -s, -1.0, 0, s, c, 0.5], dtype=f32)
+
+    assert pick2(ident) == 3 and pick2(rot_y(0.0, 1.05)) == 3   # plain layout, two voxels per lane, along z
+    assert pick2(rot_y(3.0, 1.02)) == 6                         # bench.py's matrix: 83 % re-gathers along z, 2 % along y
+    assert pick2(rot_y(5.0)) == 6 and pick2(rot_y(10.0)) == 6   # rotations about y leave the y axis quiet
+    assert pick2(rot_x(5.0)) == 5                               # about x both axes drift: row pairs + reuse, two voxels
+    assert pick2(rot_x(30.0)) == 1                              # large: row pairs, one voxel per lane
+    assert pick2(rot_y(45.0)) == 6 or pick2(rot_y(45.0)) == 1
+    for m in (ident, rot_y(3.0, 1.02), rot_x(5.0), rot_y(20.0)):
+        assert pick2(m, wide=0) == pick(m)                      # narrow targets: the one-voxel kernel of that layout
