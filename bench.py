@@ -222,7 +222,7 @@ def auxiliary_kernels(torch, mdev, eng, img, psf):
     return out
 
 
-def batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, psf_a, psf_b, fence, distributed):
+def batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, psf_a, psf_b, fence, distributed, control):
     """BASELINE.json configs[4] per regMode: what ">= 7x at 8 GPUs" is judged on.  regMode 3 (independent time points,
     `lanes` in flight per GPU), regMode 2 (the chained mode sh_spimFusionBatch.sh:21 runs: token ring over the ranks) and
     regMode 3 with 16-bit TIFF stacks read and written inside the timed region.  Every time point ends in the FIVE projection
@@ -265,8 +265,9 @@ def batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, 
 
     base = ("reg3d (affMethod 6) + joint dual-view RL (20 it) + XY / YZ / ZX MIPs + 36-angle 3-D MIPs about x and y per time "
             "point, 512x512x256, all projections gathered to rank 0")
+    # RCCL carries the gather of the projections and nothing else: the 12 / 24 floats of regMode 1 / 2 go over `control`
     common = dict(load_pair=lambda t: (img_a, view_b), reg_fn=pipe.reg_fn, check_fn=pipe.check_fn, mip_shape=pipe.mip_shape,
-                  device=coll_dev)
+                  device=coll_dev, control_group=control, control_device="cpu" if control is not None else None)
     if lanes > 1:
         # `lanes` time points in flight per GPU, one host thread each with its own engine: the kernels of one fill the host
         # round trips between the dependent cost evaluations of the other
@@ -382,6 +383,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    # host-side control messages of the batch (regMode-1 matrix, regMode-2 chain token: 12 / 24 floats) travel over gloo even
+    # when the collectives are RCCL's: RCCL is used for the gather of the projections (and this file's timing all-reduce) only
+    control = dist.new_group(backend="gloo") if distributed and args.dist_backend == "nccl" else None
 
     from microimagelib_amd import _lib, device as mdev
     lib = _lib.load()
@@ -583,7 +587,8 @@ def main():
     # iterations) and projects; the projections are gathered to rank 0 (the only exchange).
     if args.batch_time_points_per_gpu > 0 and not args.no_extra:
         from microimagelib_amd import batch
-        figs = batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, psf_a, psf_b, fence, distributed)
+        figs = batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, psf_a, psf_b, fence, distributed,
+                             control)
         if rank == 0:
             result["extra"]["batch_config5"] = figs.get("regmode3")
             result["extra"]["batch_config5_by_mode"] = figs

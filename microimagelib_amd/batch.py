@@ -188,7 +188,8 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
                 fuse_pair: Callable[[object, object, int], Tuple[object, torch.Tensor]],
                 policy: RegPolicy, reg_fn: RegFn, check_fn: CheckFn, mip_shape: Tuple[int, int],
                 sink: Optional[Callable[[int, object, np.ndarray, np.ndarray], None]] = None,
-                device="cpu", group=None, overlap: bool = False, lanes: int = 1) -> Optional[torch.Tensor]:
+                device="cpu", group=None, overlap: bool = False, lanes: int = 1, control_group=None,
+                control_device=None) -> Optional[torch.Tensor]:
     """Run the batch over this rank's share of `time_points`.
 
     load_pair(t) -> (view A, view B) already resized / rotated; fuse_pair(A, B_registered, t) -> (decon, XY MIP);
@@ -209,11 +210,20 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
     in the gaps; a second time point's kernels fill them.  `fuse_pair` must then be a SEQUENCE of `lanes` callables (each
     with its own engine / estimate buffer: FusionPipeline per lane); `load_pair`, `reg_fn`, `check_fn` and `sink` are
     called from several threads.  Every time point is processed exactly as with one lane: same results.
+    control_group / control_device: where the few floats of host-side state travel (the regMode-1 matrix, the regMode-2 chain
+    token): by default the same group / device as the gather.  On the GPU node the driver passes a gloo group and "cpu", so
+    that RCCL carries the gather of the projections and nothing else (north_star: "RCCL ... used only to gather the final MIP
+    stack") and a 24-float token never waits behind a device-side point-to-point kernel.
     Returns the time-ordered MIP stack on rank 0."""
     rank, world = _world(group)
     time_points = list(time_points)
+    if control_group is None:
+        control_group = group
+    if control_device is None:
+        control_device = device if control_group is group else "cpu"
     if policy.reg_mode == 2 and world > 1:
-        return _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group)
+        return _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group,
+                            control_group, control_device)
     if policy.reg_mode == 1:
         # register the test time point once (rank 0), then every rank applies that matrix (:719-751)
         tmx = None
@@ -221,7 +231,7 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
             t_test = policy.test_time_point if policy.test_time_point is not None else time_points[0]
             a, b = load_pair(t_test)
             _, tmx, _ = register_pair(policy, reg_fn, check_fn, a, b, first=True)
-        tmx = broadcast_matrix(tmx, 0, device=device, group=group)
+        tmx = broadcast_matrix(tmx, 0, device=control_device, group=control_group)
         policy = RegPolicy(reg_mode=0, reg_choice=0, aff_method=policy.aff_method, ftol=policy.ftol,
                            it_limit=policy.it_limit, cost_bar=policy.cost_bar, i_tmx=tmx)
     local: Dict[int, torch.Tensor] = {}
@@ -312,7 +322,8 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
     return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
 
 
-def _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group):
+def _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group,
+                 control_group=None, control_device=None):
     """regMode 2 on several ranks: a token ring.  The matrix chain (running 0.8 / 0.2 average, fall-back to the previous
     matrix, src/spim_fusion_batch.cpp:786-808) is inherently sequential: time point i cannot register before i - 1 has.
     The chain STATE -- the weighted and the previous matrix, 24 floats -- travels from the owner of time point i - 1 to the
@@ -322,6 +333,8 @@ def _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mi
     the next rank.  Registrations stay serial (the reference's semantics), results equal the single-rank run's.
     Throughput bound with registration share r of a time point: 1 / (r + (1 - r) / N) of one GPU's."""
     rank, world = _world(group)
+    if control_group is None:
+        control_group, control_device = group, device
     n = len(time_points)
     local: Dict[int, torch.Tensor] = {}
     sends = []
@@ -330,16 +343,16 @@ def _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mi
             continue
         a, b = load_pair(t)  # before the token arrives: overlaps with the registrations upstream
         if i > 0:
-            state = torch.zeros(24, dtype=torch.float32, device=device)
-            dist.recv(state, src=(i - 1) % world, group=group)
+            state = torch.zeros(24, dtype=torch.float32, device=control_device)
+            dist.recv(state, src=(i - 1) % world, group=control_group)
             got = state.cpu().numpy()
             policy.weighted, policy.previous = got[:12].copy(), got[12:].copy()
         b_reg, tmx, rec = register_pair(policy, reg_fn, check_fn, a, b, first=(i == 0))
         if i + 1 < n:
-            state = torch.zeros(24, dtype=torch.float32, device=device)
+            state = torch.zeros(24, dtype=torch.float32, device=control_device)
             state[:12].copy_(torch.from_numpy(np.asarray(policy.weighted, dtype=np.float32).reshape(12)))
             state[12:].copy_(torch.from_numpy(np.asarray(policy.previous, dtype=np.float32).reshape(12)))
-            sends.append((dist.isend(state, dst=(i + 1) % world, group=group), state))  # keep the tensor alive
+            sends.append((dist.isend(state, dst=(i + 1) % world, group=control_group), state))  # keep the tensor alive
         decon, mip = fuse_pair(a, b_reg, t)
         local[t] = mip
         if sink is not None:

@@ -292,8 +292,11 @@ def _products_worker(rank, world, port, outdir, reg_mode):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         tps = [3, 4, 5, 6, 7]
+        # the chain token / the regMode-1 matrix travel over their own (gloo) group, as bench.py sets it up next to RCCL
+        control = dist.new_group(backend="gloo")
         stacks = batch.run_sharded(tps, lambda t: (t, t), lambda a, b, t: (None, _product_values(t)),
-                                   batch.RegPolicy(reg_mode=reg_mode, reg_choice=2), _fake_reg([]), lambda m: True, PRODUCTS)
+                                   batch.RegPolicy(reg_mode=reg_mode, reg_choice=2), _fake_reg([]), lambda m: True, PRODUCTS,
+                                   control_group=control, control_device="cpu")
         if rank == 0:
             torch.save({"stacks": stacks, "gather": dict(batch.last_gather)}, os.path.join(outdir, "stacks.pt"))
         else:
@@ -303,7 +306,7 @@ def _products_worker(rank, world, port, outdir, reg_mode):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("reg_mode", [3, 2])
+@pytest.mark.parametrize("reg_mode", [3, 2, 1])
 def test_all_projection_products_two_ranks_match_single_rank(tmp_path, reg_mode):
     """XY, YZ, ZX and both 36-angle 3-D MIP stacks travel as ONE record per time point in ONE gather; rank 0 ends up with
     the five time-ordered stacks of the single-rank run (also through the regMode-2 token ring)."""
