@@ -190,6 +190,32 @@ def test_concurrent_host_threads_get_the_serial_bits(api):
         assert np.array_equal(out.view(np.uint32), serial[key].view(np.uint32)), (tag, r, key)
 
 
+def test_last_call_split_accounts_for_the_call(api):
+    """mil_decon_last_call_split (include/mil_device.h): the five parts of this thread's last decon_* call -- engine + buffers,
+    OTFs, upload + pad + initial estimate, RL loop, crop + download -- are non-negative, add up to deconRecords[9] - [6], and
+    the loop part is deconRecords[8]; a second call with the same PSF finds its OTFs cached."""
+    import ctypes as C
+    from microimagelib_amd import _lib
+    lib = _lib.load()
+    g = np.load(os.path.join(GOLD, "decon_dv_small.npz"))
+
+    def split():
+        out = (C.c_double * 5)()
+        assert lib.mil_decon_last_call_split(out) == 0
+        return np.array(out[:])
+    for dual in (False, True):
+        for attempt in range(2):
+            if dual:
+                _, rec = api.decon_dualview(g["img1"], g["img2"], g["psf1"], g["psf2"], 3)
+            else:
+                _, rec = api.decon_singleview(g["img1"], g["psf1"], 3)
+            s = split()
+            assert (s >= 0).all() and s[3] > 0
+            assert abs(s.sum() - (float(rec[9]) - float(rec[6]))) < 2e-3 + 0.05 * float(rec[9])
+            assert abs(s[3] - float(rec[8])) < 1e-3
+        assert s[1] < 2e-3  # the second call: OTFs come from the engine's cache
+
+
 def test_memory_mode_2_runs_as_mode_1(api):
     g = np.load(os.path.join(GOLD, "decon_sv_psf_eq_fft.npz"))
     out, rec = api.decon_singleview(g["img"], g["psf"], 2, gpu_mem_mode=2)
