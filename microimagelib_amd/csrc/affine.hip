@@ -61,12 +61,15 @@ struct Tap {
 // "in 9-bit fixed point format with 8 bits of fractional value (so 1.0 is exactly represented)"; it does not say how it
 // rounds -- round to nearest is ASSUMED here -- nor how the filter arithmetic is carried out (ours stays
 // w0*q0 + w1*q1 in float32, x then y then z).  A comparison aid for volumes produced by the CUDA build, off by default.
+// QUANT = false: the caller knows wq == 0 (the compiler otherwise evaluates the quantised weight -- an IEEE division --
+// for every tap and selects: 3 divisions per voxel, a quarter of resample_kernel's instructions).
+template <bool QUANT = true>
 __device__ __forceinline__ Tap make_tap(float t, int n, float wq) {
     float b = t - 0.5f;
     float f = floorf(b);
     Tap p;
     p.w1 = b - f;
-    if (wq > 0.0f) p.w1 = floorf(p.w1 * wq + 0.5f) / wq;
+    if (QUANT && wq > 0.0f) p.w1 = floorf(p.w1 * wq + 0.5f) / wq;
     p.w0 = 1.0f - p.w1;
     // Only called for t inside the validity window, so i = floor(t - 0.5) lies in [-1, n-1]: the edge clamp of the
     // reference's texture fetch reduces to one max and one min.
@@ -113,6 +116,36 @@ __device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int
     return Z.w0 * c0 + Z.w1 * c1;
 }
 
+// The same fetch for volumes below 2 GiB whose planes hold fewer than 2^24 voxels (every volume of this pipeline): ONE 32-bit
+// byte offset per tap row -- two 24-bit multiplies and adds instead of 64-bit multiply-adds per pointer -- through a buffer
+// descriptor.  Same taps, same float32 operations in the same order: the same bits.  (resample_kernel spent 195 vector
+// instructions per voxel, most of them address arithmetic: it was bound by them, not by its four gathers.)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fetch_linear_small(__amdgpu_buffer_rsrc_t rsrc, int sx, int sy, int sz, float tx, float ty,
+                                                    float tz, float wq) {
+    const Tap X = make_tap<false>(tx, sx, wq), Y = make_tap<false>(ty, sy, wq), Z = make_tap<false>(tz, sz, wq);  // wq == 0 (host check)
+    const int b = X.i0 < sx - 2 ? X.i0 : sx - 2;  // sx >= 2 (host check)
+    const bool lo0 = X.i0 == b, lo1 = X.i1 == b;
+    const unsigned plane = (unsigned)__mul24(sx, sy);
+    const unsigned z0 = (unsigned)__mul24(Z.i0, (int)plane), z1 = (unsigned)__mul24(Z.i1, (int)plane);
+    const unsigned y0 = (unsigned)__mul24(Y.i0, sx) + (unsigned)b, y1 = (unsigned)__mul24(Y.i1, sx) + (unsigned)b;
+    auto pair = [&](unsigned o) {
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(o << 2), 0, 0);
+        return Pair{__uint_as_float(v.x), __uint_as_float(v.y)};
+    };
+    const Pair q00 = pair(z0 + y0), q01 = pair(z0 + y1), q10 = pair(z1 + y0), q11 = pair(z1 + y1);
+    const float c00 = X.w0 * (lo0 ? q00.lo : q00.hi) + X.w1 * (lo1 ? q00.lo : q00.hi);
+    const float c01 = X.w0 * (lo0 ? q01.lo : q01.hi) + X.w1 * (lo1 ? q01.lo : q01.hi);
+    const float c10 = X.w0 * (lo0 ? q10.lo : q10.hi) + X.w1 * (lo1 ? q10.lo : q10.hi);
+    const float c11 = X.w0 * (lo0 ? q11.lo : q11.hi) + X.w1 * (lo1 ? q11.lo : q11.hi);
+    const float c0 = Y.w0 * c00 + Y.w1 * c01;
+    const float c1 = Y.w0 * c10 + Y.w1 * c11;
+    return Z.w0 * c0 + Z.w1 * c1;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t small_rsrc(const float *src, int sx, int sy, int sz) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, sx * sy * sz * 4, 0x00020000);
+}
+
 // Plane cache of the cost kernel.  A lane walks z; for the near-axis-aligned matrices registration visits, the lower
 // source plane of step z+1 is the upper plane of step z (same row pair, same x pair), so its two 8-byte gathers were
 // already fetched.  Reuse is decided by ADDRESS equality -- it never changes a value, only skips a gather -- and cuts
@@ -151,7 +184,8 @@ __device__ __forceinline__ float fetch_linear_cached(const float *__restrict__ s
 
 // affinetransformkernel, reference include/cukernel.cuh:501-524 (window 0 <= t < s2).
 // STRICT: the 2-D variant tests 0 < t (affineTransform2Dkernel, include/cukernel.cuh:558-573).
-template <bool STRICT>
+// SMALL: source below 2 GiB with planes below 2^24 voxels and sx >= 2 (small_source()): fetch_linear_small.
+template <bool STRICT, bool SMALL>
 __global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restrict__ out,
                                                                const float *__restrict__ src, AffineArgs a) {
     const int x = blockIdx.x * kTileX + (threadIdx.x & (kTileX - 1));
@@ -164,8 +198,10 @@ __global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restri
     const float tz = coord(a.m + 8, ix, iy, iz);
     float v = 0.0f;
     const bool lower = STRICT ? (tx > 0 && ty > 0 && tz > 0) : (tx >= 0 && ty >= 0 && tz >= 0);
-    if (lower && tx < (float)a.sx && ty < (float)a.sy && tz < (float)a.sz)
-        v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
+    if (lower && tx < (float)a.sx && ty < (float)a.sy && tz < (float)a.sz) {
+        if constexpr (SMALL) v = fetch_linear_small(small_rsrc(src, a.sx, a.sy, a.sz), a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
+        else v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
+    }
     out[(size_t)x + (size_t)a.tx * ((size_t)y + (size_t)a.ty * z)] = v;
 }
 
@@ -180,7 +216,7 @@ __global__ __launch_bounds__(kBlockThreads) void resample_kernel(float *__restri
 // touches stay few (small angles: 2-3 cache lines per gather, 45 at 45 degrees), 1 x 64 when the march direction has
 // become the source's x axis (near 90 / 270 degrees), 8 x 8 in between.  The z lanes of an (x, y) meet in a wave-level
 // maximum, the z segments of the grid in the atomic.
-template <int LX>
+template <int LX, bool SMALL>
 __global__ __launch_bounds__(kBlockThreads) void resample_mip_kernel(int *__restrict__ out, const float *__restrict__ src,
                                                                      AffineArgs a, int segments) {
     constexpr int LZ = 64 / LX;
@@ -200,8 +236,10 @@ __global__ __launch_bounds__(kBlockThreads) void resample_mip_kernel(int *__rest
             const float ty = coord(a.m + 4, ix, iy, iz);
             const float tz = coord(a.m + 8, ix, iy, iz);
             float v = 0.0f;
-            if (tx >= 0 && ty >= 0 && tz >= 0 && tx < (float)a.sx && ty < (float)a.sy && tz < (float)a.sz)
-                v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
+            if (tx >= 0 && ty >= 0 && tz >= 0 && tx < (float)a.sx && ty < (float)a.sy && tz < (float)a.sz) {
+                if constexpr (SMALL) v = fetch_linear_small(small_rsrc(src, a.sx, a.sy, a.sz), a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
+                else v = fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
+            }
             best = (best > v) ? best : v;
         }
     }
@@ -283,6 +321,14 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
     corr_publish<kBlockThreads>(a0, a1, tail, lds, &last);
 }
 
+// fetch_linear_small applies: exact float32 weights (no texture-unit emulation), 32-bit byte offsets, 24-bit multiplies, 8-byte
+// pairs inside a row
+bool small_source(Dims s) {
+    static const bool off = getenv("MIL_RESAMPLE_SMALL") && getenv("MIL_RESAMPLE_SMALL")[0] == '0';
+    return !off && texture_weight_bits() == 0 && s.nx >= 2 && s.count() * 4 < (1ll << 31) && s.nx * s.ny < (1ll << 24) &&
+           s.nz < (1ll << 24);
+}
+
 AffineArgs make_args(Dims t, Dims s, const Affine12 &m) {
     if (t.nx <= 0 || t.ny <= 0 || t.nz <= 0 || s.nx <= 0 || s.ny <= 0 || s.nz <= 0)
         throw Error(-1, "affine kernel: empty volume");
@@ -316,8 +362,11 @@ void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims,
     AffineArgs a = make_args(out_dims, src_dims, m);
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, a.tz);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "affine_resample: volume exceeds launch limits");
-    if (strict_window) hipLaunchKernelGGL(resample_kernel<true>, grid, dim3(kBlockThreads), 0, s, out, src, a);
-    else hipLaunchKernelGGL(resample_kernel<false>, grid, dim3(kBlockThreads), 0, s, out, src, a);
+    const bool small = small_source(src_dims);
+    if (strict_window && small) hipLaunchKernelGGL((resample_kernel<true, true>), grid, dim3(kBlockThreads), 0, s, out, src, a);
+    else if (strict_window) hipLaunchKernelGGL((resample_kernel<true, false>), grid, dim3(kBlockThreads), 0, s, out, src, a);
+    else if (small) hipLaunchKernelGGL((resample_kernel<false, true>), grid, dim3(kBlockThreads), 0, s, out, src, a);
+    else hipLaunchKernelGGL((resample_kernel<false, false>), grid, dim3(kBlockThreads), 0, s, out, src, a);
     MIL_HIP(hipGetLastError());
 }
 
@@ -332,9 +381,13 @@ void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims,
     if (grid.y > 65535) throw Error(-1, "resample_mip_z: plane exceeds launch limits");
     MIL_HIP(hipMemsetAsync(out_plane, 0, (size_t)a.tx * a.ty * sizeof(float), s));
     int *o = reinterpret_cast<int *>(out_plane);
-    if (lx == 64) hipLaunchKernelGGL(resample_mip_kernel<64>, grid, dim3(kBlockThreads), 0, s, o, src, a, segments);
-    else if (lx == 8) hipLaunchKernelGGL(resample_mip_kernel<8>, grid, dim3(kBlockThreads), 0, s, o, src, a, segments);
-    else hipLaunchKernelGGL(resample_mip_kernel<1>, grid, dim3(kBlockThreads), 0, s, o, src, a, segments);
+#define MIL_MIP(LX)                                                                                                   \
+    if (small_source(src_dims)) hipLaunchKernelGGL((resample_mip_kernel<LX, true>), grid, dim3(kBlockThreads), 0, s, o, src, a, segments); \
+    else hipLaunchKernelGGL((resample_mip_kernel<LX, false>), grid, dim3(kBlockThreads), 0, s, o, src, a, segments);
+    if (lx == 64) { MIL_MIP(64) }
+    else if (lx == 8) { MIL_MIP(8) }
+    else { MIL_MIP(1) }
+#undef MIL_MIP
     MIL_HIP(hipGetLastError());
 }
 
