@@ -697,8 +697,8 @@ namespace {
 // how often, per z step, some lane of a 64-wide wave crosses a source column, row or plane out of turn: the crossing rate
 // of one lane (|m2|, |m6|, |m10 - 1| per step) times the number of distinct phases the wave's lanes carry
 // (1 + 64 * distance of the per-x increment m0 / m4 / m8 from an integer, at most 64).
-//   < 0.08  plain layout + plane reuse           (translations, pure scales, rotations up to ~2 degrees)
-//   < 0.6   row pairs + plane reuse              (the usual registration matrix: a few degrees AND a few per cent)
+//   < 0.05  plain layout + plane reuse           (translations, pure scales, rotations up to ~1 degree)
+//   < 2.0   row pairs + plane reuse              (the usual registration matrix: a few degrees AND a few per cent)
 //   else    row pairs, both planes gathered      (large rotations)
 std::atomic<int> g_forced_kernel{-1};  // test / profiling aid (process-wide), corr_padded_force_kernel(): 0-2 one voxel per lane, 3-5 two, 6 two + marching along y
 
@@ -713,12 +713,19 @@ void exception_rates(const float *m, double &along_z, double &along_y) {
     along_y = std::fabs((double)m[1]) * px + std::fabs((double)m[5] - 1.0) * py + std::fabs((double)m[9]) * pz;
 }
 
+// Thresholds fitted to 337 matrices a real optimisation visits, each timed with kernels 3, 6, 5, 4 at 512 x 512 x 256
+// (tools/tune_corr_pick.py, profiles/r04/reg_cost_pick.txt): the rule averages 0.1636 ms where the per-matrix best of the four
+// is 0.1602 (round 3's thresholds 0.08 / 0.6 / 0.08 / 0.5, no spread test: 0.1687).
+constexpr double kPlainMaxRate = 0.05;       // plain layout + plane reuse below this re-gather rate along z
+constexpr double kPairsReuseMaxRate = 2.0;   // row pairs keep their plane reuse up to here
+constexpr double kMarchYMaxRate = 0.05;      // kernel 6: re-gather rate along y below this, and below the rate along z,
+constexpr double kMarchYMaxSpread = 6.0;     // ... and the lanes of a wave within this many source rows + planes
 int pick_layout(const float *m, bool has_pairs) {
     if (!has_pairs) return 0;
     double rate, rate_y;
     exception_rates(m, rate, rate_y);
-    if (!(rate >= 0.08)) return 0;  // also NaN
-    return rate < 0.6 ? 2 : 1;
+    if (!(rate >= kPlainMaxRate)) return 0;  // also NaN
+    return rate < kPairsReuseMaxRate ? 2 : 1;
 }
 
 // 0 plain + reuse | 1 row pairs | 2 row pairs + reuse: one voxel per lane; 3 / 4 / 5: the same with two voxels per lane
@@ -739,7 +746,12 @@ int pick_kernel(const float *m, bool has_pairs, bool wide) {
     if (wide) {
         double rz, ry;
         exception_rates(m, rz, ry);
-        if (ry < 0.08 && ry < 0.5 * rz) return 6;  // a clear win only: at equal rates the z-marching forms stay
+        // ... and only while the 64 lanes of a wave stay within a few source rows / planes: spread wider (rotations beyond
+        // ~5 degrees about y or z) every gather touches a line per lane whichever axis the wave marches along, and the row
+        // pairs' half instruction count wins (three matrices of the trajectory sample cost 0.56-0.70 ms with kernel 6 against
+        // 0.39-0.45 with kernel 5: profiles/r03/reg_cost_pick_on_trajectory_matrices.txt, profiles/r04/reg_cost_pick.txt)
+        const double spread = 64.0 * (std::fabs((double)m[4]) + std::fabs((double)m[8]));
+        if (ry < kMarchYMaxRate && ry < rz && spread < kMarchYMaxSpread) return 6;
     }
     const int layout = pick_layout(m, has_pairs);
     return layout + ((wide && layout != 1) ? 3 : 0);

@@ -55,14 +55,16 @@ for m in mats:
             mdev.corr_sums(tgt, pad, m)
         t[k] = (time.perf_counter() - t0) / n * 1e3
     rz, ry = rates([float(v) for v in m])
-    rows.append((rz, ry, t))
+    rows.append((rz, ry, t, [float(v) for v in m]))
 mdev.corr_padded_force_kernel(-1)
 auto = np.mean([r[2][-1] for r in rows])
 best = np.mean([min(r[2][k] for k in (3, 6, 5, 4)) for r in rows])
 print(f"{len(rows)} matrices: per-matrix choice {auto:.4f} ms, best of (3, 6, 5, 4) per matrix {best:.4f} ms, "
       f"always 3: {np.mean([r[2][3] for r in rows]):.4f}, always 6: {np.mean([r[2][6] for r in rows]):.4f}, "
       f"always 5: {np.mean([r[2][5] for r in rows]):.4f}, always 4: {np.mean([r[2][4] for r in rows]):.4f}")
+if os.environ.get("TUNE_JSON"):
+    json.dump([{"m": r[3], "rz": r[0], "ry": r[1], "t": {str(k): v for k, v in r[2].items()}} for r in rows], open(os.environ["TUNE_JSON"], "w"))
 print("  rz      ry     auto    k3     k6     k5     k4   best")
-for rz, ry, t in sorted(rows, key=lambda r: min(r[0], r[1])):
+for rz, ry, t, _ in sorted(rows, key=lambda r: min(r[0], r[1])):
     b = min((3, 6, 5, 4), key=lambda k: t[k])
     print(f"{rz:6.3f} {ry:6.3f}  {t[-1]:.3f}  {t[3]:.3f}  {t[6]:.3f}  {t[5]:.3f}  {t[4]:.3f}   k{b}")
