@@ -276,7 +276,9 @@ def batch_figures(torch, dist, batch, mdev, args, world, rank, coll_dev, img_a, 
         run3 = lambda tps: batch.run_sharded(tps, fuse_pair=pipe.fuse_pair, policy=policy(3), overlap=True, **common)
     measure("regmode3", "spimFusionBatch loop, regMode 3 (independent time points): " + base + "; views resident in HBM",
             run3, list(range(world * lanes)), {"time_points_in_flight_per_gpu": lanes})
-    run2 = lambda tps: batch.run_sharded(tps, fuse_pair=pipe.fuse_pair, policy=policy(2), **common)
+    # one rank: the joint RL + projections of time point i run on a helper thread while i + 1 is registered (the chain only
+    # orders the registrations); several ranks: the token ring overlaps them across ranks
+    run2 = lambda tps: batch.run_sharded(tps, fuse_pair=pipe.fuse_pair, policy=policy(2), overlap=(world == 1), **common)
     measure("regmode2", "spimFusionBatch loop, regMode 2 (chained start matrices, the mode of sh_spimFusionBatch.sh:21; token "
             "ring over the ranks, registrations serial by definition): " + base + "; views resident in HBM",
             run2, list(range(world)), {"time_points_in_flight_per_gpu": 1})

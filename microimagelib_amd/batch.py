@@ -203,7 +203,8 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
     reg_fn must return a registered volume that does not alias the one it returned for the previous time point (the worker
     reads b_reg of i while i + 1 is registered).  fuse_pair may reuse one output buffer: one deconvolution is in flight at
     a time and its MIP is cloned before the next starts.  Results are the same, only the order of host-side side effects
-    within a rank changes.  Modes 0, 1, 3.
+    within a rank changes.  Modes 0, 1, 3, and mode 2 on ONE rank (the chain orders the registrations, which stay on the calling
+    thread; across ranks the token ring does the overlapping).
     lanes > 1 (modes 0, 1, 3): this rank works on `lanes` time points AT ONCE, one host thread each -- the same idea as the
     command-line tool's worker threads (cli/spim_fusion_batch_main.cpp: a device listed twice).  A registration is a chain
     of ~10^3 dependent cost evaluations with a host round trip between any two, so one time point alone leaves the GPU idle

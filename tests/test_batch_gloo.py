@@ -150,8 +150,9 @@ def test_chained_mode_three_ranks_carries_the_running_average(tmp_path):
     assert [len(r["log"]) for r in rs] == [2, 2, 1]  # 5 time points dealt 3, 4, 5, 6, 7 -> ranks 0, 1, 2, 0, 1
 
 
-def test_overlapped_pipeline_gives_the_same_results():
-    """overlap=True: fuse + sink of time point i on a helper thread while i + 1 registers -- same matrices, same MIPs,
+@pytest.mark.parametrize("reg_mode", [3, 2])
+def test_overlapped_pipeline_gives_the_same_results(reg_mode):
+    """(regMode 2 on one rank: the chain orders the registrations, which stay on the calling thread.)  overlap=True: fuse + sink of time point i on a helper thread while i + 1 registers -- same matrices, same MIPs,
     every time point sunk exactly once, and the helper really ran concurrently with a registration."""
     import threading
     import time as _time
@@ -180,7 +181,7 @@ def test_overlapped_pipeline_gives_the_same_results():
         def sink(t, decon, tmx, rec):
             assert t not in sunk
             sunk[t] = (tmx.tolist(), threading.current_thread().name)
-        stack = batch.run_sharded([3, 4, 5, 6], lambda t: (t, t), fuse_pair, batch.RegPolicy(reg_mode=3, reg_choice=2),
+        stack = batch.run_sharded([3, 4, 5, 6], lambda t: (t, t), fuse_pair, batch.RegPolicy(reg_mode=reg_mode, reg_choice=2),
                                   reg_fn, lambda m: True, MIP_SHAPE, sink=sink, overlap=overlap)
         return log, sunk, stack, seen["concurrent"]
 
