@@ -419,14 +419,14 @@ def main():
                   mdev.DeconEngine.TIMER_FFT)
     # Inside the timed region only the roofline kernel is bracketed with HIP events on the engine's stream
     # (fused backend: z_conv = z transform, OTF product, inverse z transform in one kernel -- the largest single
-    # symbol in the rocprofv3 kernel stats; rocFFT backend: the OTF product), and only every 2nd launch of it
-    # (one per step).  An event pair is a pair of stream markers: the
+    # symbol in the rocprofv3 kernel stats; rocFFT backend: the OTF product), and only every 8th launch of it
+    # (one per four steps: 25 samples at K = 100, 5 at K = 20; one per step cost 0.6 % of the timed region).  An event pair is a pair of stream markers: the
     # rocprofv3 trace shows 0 us between back-to-back kernels and 6-10 us across a marker, so bracketing all 8
     # launches of a step would cost several percent of it.  The other families are timed in a second,
     # un-clocked pass of the same K steps.
     dom_timer = mdev.DeconEngine.TIMER_CMUL  # fused: z_conv, the largest single kernel symbol of the step
     if not os.environ.get("MIL_BENCH_NO_EVENTS"):  # diagnostic: how much the in-region markers cost
-        eng.timer_enable(dom_timer, 2)
+        eng.timer_enable(dom_timer, int(os.environ.get("MIL_BENCH_EVENT_STRIDE", "8")))
 
     def fence():
         torch.cuda.synchronize()
