@@ -626,6 +626,267 @@ __global__ __launch_bounds__(kThreads) void corr_pair_kernel(const float *__rest
     corr_pair_body<PAIRS, REUSE, MARCHY>(tgt, srcp, a, tail, old_grid_x, lds, &last);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Chunked form of the two-voxel kernels (round 5).  The tiled kernels above are bound by LATENCY, not bytes: a wave has ONE
+// step in flight, a step is one memory round trip under load (~1.4 us), and every 16-step tile adds a workgroup launch, a
+// cold first step (lower + upper plane, target) and two publish round trips -- about 8 us of the ~23 us a tile occupies its
+// slot (z steps per tile 8 / 16 / 32: 0.198 / 0.146 / 0.145 ms, the last one losing to the 3.2 -> 4 rounds of its 4 096
+// tiles on 1 280 slots what it gains per tile).  Here the grid is what the chip holds at once and a workgroup walks a
+// CONTIGUOUS piece of the (column, step) sequence -- columns of 128 x 4 voxels, steps along the marching axis, the pieces
+// equal to within one step whatever the volume -- so a slot pays one launch, one or two cold steps and ONE publish per
+// evaluation.  The float32 voxel values are those of every other kernel; a lane's float64 sums now run over its whole piece
+// (~100 steps) and the number of pieces follows the device, so the two sums agree with the tiled kernels' to ~1e-15 relative
+// (like kernel 6), and are bit-reproducible from run to run on one device.
+#ifndef CHUNK_WAVES
+#define CHUNK_WAVES 5
+#endif
+constexpr int kSubRun = 24;  // steps between two decisions "may this wave drop the window tests" (a multiple of 3: the
+                             // plane roles of the rotating register sets are back in place)
+
+template <bool PAIRS, bool REUSE, bool MARCHY>
+__global__ __launch_bounds__(kThreads, CHUNK_WAVES) void corr_chunk_kernel(const float *__restrict__ tgt,
+                                                            const float *__restrict__ srcp, PaddedArgs a, CorrTail tail,
+                                                            unsigned total_steps, int run_len) {
+    static_assert(!MARCHY || (!PAIRS && REUSE), "the y-marching form exists for the plain layout with reuse");
+    __shared__ double lds[4 * kTileY];
+    __shared__ int last;
+    const int lane = threadIdx.x & (kTileX - 1), wave = threadIdx.x / kTileX;
+    const unsigned long long tot = total_steps;
+    const unsigned lo = (unsigned)(tot * blockIdx.x / gridDim.x), hi = (unsigned)(tot * (blockIdx.x + 1) / gridDim.x);
+    const f32x2 half2 = {0.5f, 0.5f};
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(srcp), 0, (int)a.bytes, 0x00020000);
+    const unsigned sRow = (unsigned)a.row4, sPlane = (unsigned)a.plane4, sBoth = (unsigned)(a.plane4 + a.row4);
+    const char *tbase = reinterpret_cast<const char *>(tgt);
+    const unsigned tstep = MARCHY ? 4u * (unsigned)a.tx : 4u * (unsigned)a.tx * (unsigned)a.ty;
+    const unsigned sStep = MARCHY ? sRow : sPlane, sSide = MARCHY ? sPlane : sRow;
+    double ssA = 0.0, stA = 0.0, ssB = 0.0, stB = 0.0;
+
+    struct Vox {
+        float wx1, wy1, wz1;
+        unsigned off;
+        bool in;
+        float tv;
+    };
+    auto inside = [&](float tx_, float ty_, float tz_) {
+        return tx_ > 0 && tx_ < a.sxf && ty_ > 0 && ty_ < a.syf && tz_ > 0 && tz_ < a.szf;
+    };
+
+    for (unsigned L = lo; L < hi;) {
+        const unsigned col = L / (unsigned)run_len;
+        const int s0 = (int)(L - col * (unsigned)run_len);
+        const int s1 = (int)min((unsigned)run_len, (unsigned)s0 + (hi - L));
+        L += (unsigned)(s1 - s0);
+        const int bx = (int)(col % (unsigned)a.gx), by = (int)(col / (unsigned)a.gx);
+        const int x = bx * 2 * kTileX + lane;  // voxel A; voxel B sits kTileX further on; tx % 128 == 0 (host check)
+        const int fixed = by * kTileY + wave;  // this wave's coordinate across the marching axis (y, or z when marching along y)
+        if (fixed >= (MARCHY ? a.tz : a.ty)) continue;  // wave-uniform
+        const float ifix = (float)fixed;
+        const f32x2 ixs = {(float)x, (float)(x + kTileX)};
+        // t = ((m0*x + m1*y) + m2*z) + m3, then + 0.5: the reference's left-to-right float32 evaluation (corr_pair_body)
+        const f32x2 PX = ixs * a.m[0], PY = ixs * a.m[4], PZ = ixs * a.m[8];
+        const float cx = (MARCHY ? a.m[2] : a.m[1]) * ifix, cy = (MARCHY ? a.m[6] : a.m[5]) * ifix, cz = (MARCHY ? a.m[10] : a.m[9]) * ifix;
+        const f32x2 HX = PX + (f32x2){cx, cx}, HY = PY + (f32x2){cy, cy}, HZ = PZ + (f32x2){cz, cz};  // z-marching form only
+        auto coords = [&](int step, f32x2 &TX, f32x2 &TY, f32x2 &TZ) {
+            const float is = (float)step;
+            if constexpr (MARCHY) {
+                const float yx = a.m[1] * is, yy = a.m[5] * is, yz = a.m[9] * is;
+                TX = (((PX + (f32x2){yx, yx}) + (f32x2){cx, cx}) + (f32x2){a.m[3], a.m[3]}) + half2;
+                TY = (((PY + (f32x2){yy, yy}) + (f32x2){cy, cy}) + (f32x2){a.m[7], a.m[7]}) + half2;
+                TZ = (((PZ + (f32x2){yz, yz}) + (f32x2){cz, cz}) + (f32x2){a.m[11], a.m[11]}) + half2;
+            } else {
+                const float zx = a.m[2] * is, zy = a.m[6] * is, zz = a.m[10] * is;
+                TX = ((HX + (f32x2){zx, zx}) + (f32x2){a.m[3], a.m[3]}) + half2;
+                TY = ((HY + (f32x2){zy, zy}) + (f32x2){a.m[7], a.m[7]}) + half2;
+                TZ = ((HZ + (f32x2){zz, zz}) + (f32x2){a.m[11], a.m[11]}) + half2;
+            }
+        };
+        unsigned toff = MARCHY ? 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)s0 + (unsigned)a.ty * (unsigned)fixed))
+                               : 4u * ((unsigned)x + (unsigned)a.tx * ((unsigned)fixed + (unsigned)a.ty * (unsigned)s0));
+        // chk (wave-uniform, a scalar branch): false = every lane of the wave is known to lie in the window at this step, so
+        // the six compares and the offset substitutions are jumped over.  ONE body for both cases: as two instantiations
+        // that hand the rotating register sets to each other the kernel needed 113 registers instead of 78.
+        // ride: a lane outside the window takes the offset the reuse expects (prev + one step) instead of 0, so that it
+        // never triggers the wave-wide re-gather.
+        auto prepare = [&](bool chk, bool ride, int z, unsigned toff, const Vox &pA, const Vox &pB, Vox &A, Vox &B) {
+            f32x2 TX, TY, TZ;
+            coords(z, TX, TY, TZ);
+            const f32x2 BX = TX - half2, BY = TY - half2, BZ = TZ - half2;
+            const float fxA = floorf(BX.x), fyA = floorf(BY.x), fzA = floorf(BZ.x);
+            const float fxB = floorf(BX.y), fyB = floorf(BY.y), fzB = floorf(BZ.y);
+            A.wx1 = BX.x - fxA; A.wy1 = BY.x - fyA; A.wz1 = BZ.x - fzA;
+            B.wx1 = BX.y - fxB; B.wy1 = BY.y - fyB; B.wz1 = BZ.y - fzB;
+            constexpr int SH = PAIRS ? 3 : 2;
+            const f32x2 magic = {12582912.0f, 12582912.0f};  // index arithmetic on float bit patterns: see corr_pair_body
+            const f32x2 MX = (f32x2){fxA, fxB} + magic, MY = (f32x2){fyA, fyB} + magic, MZ = (f32x2){fzA, fzB} + magic;
+            auto mad24 = [](unsigned x, unsigned y, unsigned z) {
+                unsigned r;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(y), "v"(z));
+                return r;
+            };
+            const unsigned row = (unsigned)a.row4, plane = (unsigned)a.plane4, org = (unsigned)a.origin4m;
+            A.off = mad24(__float_as_uint(MZ.x), plane, mad24(__float_as_uint(MY.x), row, (__float_as_uint(MX.x) << SH) + org));
+            B.off = mad24(__float_as_uint(MZ.y), plane, mad24(__float_as_uint(MY.y), row, (__float_as_uint(MX.y) << SH) + org));
+            A.in = B.in = true;
+            if (chk) {
+                A.in = inside(TX.x, TY.x, TZ.x);
+                B.in = inside(TX.y, TY.y, TZ.y);
+                A.off = A.in ? A.off : (ride ? pA.off + sStep : 0u);
+                B.off = B.in ? B.off : (ride ? pB.off + sStep : 0u);
+            }
+            A.tv = *reinterpret_cast<const float *>(tbase + toff);
+            B.tv = *reinterpret_cast<const float *>(tbase + toff + 4u * kTileX);
+        };
+        auto finish = [&](const Vox &p, float r, double &ss, double &st) {
+            const float sv = __uint_as_float(p.in ? __float_as_uint(r) : 0u);
+            // float x float is exact in double, so the fused form rounds exactly like multiply-then-add
+            ss = __builtin_fma((double)sv, (double)sv, ss);
+            st = __builtin_fma((double)sv, (double)p.tv, st);
+        };
+        // May the wave drop the tests for the steps (z - 1 .. ze - 1]?  The coordinates are monotone along the marching axis
+        // under float32 evaluation: in the window at step z - 1 (the one waiting to be interpolated) and at step ze - 1 means
+        // in the window throughout.
+        auto all_inside = [&](const Vox &A, const Vox &B, int ze) {
+            f32x2 TX, TY, TZ;
+            coords(ze - 1, TX, TY, TZ);
+            return __all(A.in && B.in && inside(TX.x, TY.x, TZ.x) && inside(TX.y, TY.y, TZ.y)) != 0;
+        };
+        if constexpr (!PAIRS) {
+            auto accumulate = [&](const Vox &p, f32x2 lo0, f32x2 lo1, f32x2 up0, f32x2 up1, double &ss, double &st) {
+                const f32x2 wx = {1.0f - p.wx1, p.wx1}, wy = {1.0f - p.wy1, p.wy1}, wz = {1.0f - p.wz1, p.wz1};
+                const f32x2 p00 = wx * lo0, p01 = wx * lo1, p10 = wx * up0, p11 = wx * up1;
+                const f32x2 lower = {p00.x + p00.y, p01.x + p01.y}, upper = {p10.x + p10.y, p11.x + p11.y};
+                const f32x2 el = wy * lower, eu = wy * upper;
+                const f32x2 e = {el.x + el.y, eu.x + eu.y};
+                const f32x2 rz = wz * e;
+                finish(p, rz.x + rz.y, ss, st);
+            };
+            struct Taps { f32x2 r0, r1; };
+            auto plane = [&](unsigned off, bool upper) {
+                return Taps{gather_pair(rsrc, off, upper ? sStep : 0u), gather_pair(rsrc, off, upper ? sBoth : sSide)};
+            };
+            auto interp = [&](const Vox &p, const Taps &lo, const Taps &up, double &ss, double &st) {
+                if constexpr (MARCHY) accumulate(p, lo.r0, up.r0, lo.r1, up.r1, ss, st);
+                else accumulate(p, lo.r0, lo.r1, up.r0, up.r1, ss, st);
+            };
+            Vox cA, cB;
+            prepare(true, false, s0, toff, cA, cB, cA, cB);
+            Taps aP = plane(cA.off, false), aQ = plane(cA.off, true), aR = aQ;
+            Taps bP = plane(cB.off, false), bQ = plane(cB.off, true), bR = bQ;
+            auto step = [&](bool chk, int z, Taps &aLo, Taps &aUp, Taps &aNx, Taps &bLo, Taps &bUp, Taps &bNx) {
+                toff += tstep;
+                Vox nA, nB;
+                prepare(chk, REUSE, z, toff, cA, cB, nA, nB);
+                aNx = plane(nA.off, true);
+                bNx = plane(nB.off, true);
+                Taps al, bl;
+                if (!REUSE) {
+                    al = plane(nA.off, false);
+                    bl = plane(nB.off, false);
+                }
+                interp(cA, aLo, aUp, ssA, stA);
+                interp(cB, bLo, bUp, ssB, stB);
+                if (REUSE) {
+                    asm volatile("" : "+v"(ssA), "+v"(stA), "+v"(ssB), "+v"(stB) : : "memory");  // see corr_pair_body
+                    if (nA.off != cA.off + sStep) aUp = plane(nA.off, false);
+                    if (nB.off != cB.off + sStep) bUp = plane(nB.off, false);
+                } else {
+                    aUp = al;
+                    bUp = bl;
+                }
+                cA = nA;
+                cB = nB;
+            };
+            for (int z = s0 + 1; z < s1;) {
+                const int ze = min(z + kSubRun, s1);
+                const bool chk = !all_inside(cA, cB, ze);
+                for (; z + 2 < ze; z += 3) {
+                    step(chk, z, aP, aQ, aR, bP, bQ, bR);      // afterwards: lower = Q, upper = R
+                    step(chk, z + 1, aQ, aR, aP, bQ, bR, bP);  // lower = R, upper = P
+                    step(chk, z + 2, aR, aP, aQ, bR, bP, bQ);  // lower = P, upper = Q
+                }
+                for (; z < ze; ++z) {  // the end of a run: rotate by copying
+                    step(chk, z, aP, aQ, aR, bP, bQ, bR);
+                    aP = aQ; aQ = aR; bP = bQ; bQ = bR;
+                }
+            }
+            interp(cA, aP, aQ, ssA, stA);
+            interp(cB, bP, bQ, ssB, stB);
+        } else {
+            auto accumulate = [&](const Vox &p, f32x4 lo, f32x4 up, double &ss, double &st) {
+                const float wx0 = 1.0f - p.wx1;
+                const f32x2 wy = {1.0f - p.wy1, p.wy1}, wz = {1.0f - p.wz1, p.wz1};
+                const f32x2 lo_a = {lo.x, lo.y}, lo_b = {lo.z, lo.w}, up_a = {up.x, up.y}, up_b = {up.z, up.w};
+                const f32x2 cl = lo_a * wx0 + lo_b * p.wx1;
+                const f32x2 cu = up_a * wx0 + up_b * p.wx1;
+                const f32x2 el = wy * cl, eu = wy * cu;
+                const f32x2 e = {el.x + el.y, eu.x + eu.y};
+                const f32x2 rz = wz * e;
+                finish(p, rz.x + rz.y, ss, st);
+            };
+            Vox cA, cB;
+            prepare(true, false, s0, toff, cA, cB, cA, cB);
+            f32x4 aP = gather_quad(rsrc, cA.off, 0u), aQ = gather_quad(rsrc, cA.off, sPlane), aR = aQ;
+            f32x4 bP = gather_quad(rsrc, cB.off, 0u), bQ = gather_quad(rsrc, cB.off, sPlane), bR = bQ;
+            auto step = [&](bool chk, int z, f32x4 &aLo, f32x4 &aUp, f32x4 &aNx, f32x4 &bLo, f32x4 &bUp, f32x4 &bNx) {
+                toff += tstep;
+                Vox nA, nB;
+                prepare(chk, REUSE, z, toff, cA, cB, nA, nB);
+                aNx = gather_quad(rsrc, nA.off, sPlane);
+                bNx = gather_quad(rsrc, nB.off, sPlane);
+                f32x4 al, bl;
+                if (!REUSE) {
+                    al = gather_quad(rsrc, nA.off, 0u);
+                    bl = gather_quad(rsrc, nB.off, 0u);
+                }
+                accumulate(cA, aLo, aUp, ssA, stA);
+                accumulate(cB, bLo, bUp, ssB, stB);
+                if (REUSE) {
+                    asm volatile("" : "+v"(ssA), "+v"(stA), "+v"(ssB), "+v"(stB) : : "memory");
+                    if (nA.off != cA.off + sPlane) aUp = gather_quad(rsrc, nA.off, 0u);
+                    if (nB.off != cB.off + sPlane) bUp = gather_quad(rsrc, nB.off, 0u);
+                } else {
+                    aUp = al;
+                    bUp = bl;
+                }
+                cA = nA;
+                cB = nB;
+            };
+            for (int z = s0 + 1; z < s1;) {
+                const int ze = min(z + kSubRun, s1);
+                const bool chk = !all_inside(cA, cB, ze);
+                for (; z + 2 < ze; z += 3) {
+                    step(chk, z, aP, aQ, aR, bP, bQ, bR);
+                    step(chk, z + 1, aQ, aR, aP, bQ, bR, bP);
+                    step(chk, z + 2, aR, aP, aQ, bR, bP, bQ);
+                }
+                for (; z < ze; ++z) {
+                    step(chk, z, aP, aQ, aR, bP, bQ, bR);
+                    aP = aQ; aQ = aR; bP = bQ; bQ = bR;
+                }
+            }
+            accumulate(cA, aP, aQ, ssA, stA);
+            accumulate(cB, bP, bQ, ssB, stB);
+        }
+    }
+    // one publish per workgroup: lanes -> wave (shuffle tree) -> workgroup (waves in order) -> partial blockIdx.x
+    double ss = corr_wave_sum(ssA + ssB), st = corr_wave_sum(stA + stB);
+    if (lane == 0) {
+        lds[wave] = ss;
+        lds[kTileY + wave] = st;
+    }
+    __syncthreads();
+    double v0 = 0.0, v1 = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kTileY; ++w) {
+            v0 += lds[w];
+            v1 += lds[kTileY + w];
+        }
+    }
+    corr_publish_as<kThreads>((int)blockIdx.x, v0, v1, tail, lds, &last);
+}
+
 // dst[z+1][y+1][x+1] = (src[z][y][x], src[z][y+1][x]) with edge replication; y runs over [-1, sy-1].
 __global__ __launch_bounds__(256) void pad_rowpair_kernel(float2 *__restrict__ dst, const float *__restrict__ src,
                                                         int sx, int sy, int sz) {
@@ -737,7 +998,8 @@ int pick_layout(const float *m, bool has_pairs) {
 // along z (rotations about y, as in bench.py: 83 % against 2 % of the wave-steps re-gather), kernel 6 runs the plain layout at
 // 0.161 ms where the row pairs take 0.175 and the plain z-marching form 0.202.
 int pick_kernel(const float *m, bool has_pairs, bool wide) {
-    const int forced = g_forced_kernel;
+    int forced = g_forced_kernel;
+    if (forced >= 7 && forced <= 10) forced -= 4;  // the chunked forms of 3-6: same layouts, same per-matrix fall-backs
     if (forced == 6) return wide ? 6 : 0;
     if (forced >= 0 && forced <= 5) {
         const int layout = forced % 3;
@@ -755,6 +1017,44 @@ int pick_kernel(const float *m, bool has_pairs, bool wide) {
     }
     const int layout = pick_layout(m, has_pairs);
     return layout + ((wide && layout != 1) ? 3 : 0);
+}
+
+// The two-voxel kernels (3-6) run in their chunked form (corr_chunk_kernel) unless a tiled one is forced (0-6) or
+// MIL_CORR_CHUNK=0 asks for the tiled kernels everywhere (A/B measurements; the tiled forms return the bits of kernels 0-2).
+bool use_chunks() {
+    const int forced = g_forced_kernel;
+    if (forced >= 7 && forced <= 10) return true;
+    if (forced >= 0) return false;
+    static const bool off = getenv("MIL_CORR_CHUNK") && getenv("MIL_CORR_CHUNK")[0] == '0';
+    return !off;
+}
+
+// Workgroups of a chunked launch: what the device holds at once (occupancy of THAT kernel x compute units), but no more
+// than one per kMinChunk steps.  MIL_CORR_CHUNK_WGS_PER_CU overrides the occupancy (experiments).
+constexpr unsigned kMinChunk = 24;
+// workgroups (of four waves) per compute unit, by kernel 3 .. 6, when the registers allow as many (ms per evaluation at
+// 512 x 512 x 256, identity / 3 deg about y + 2 %, profiles/r05/reg_cost_chunked_ab.txt: kernel 3 with 4 | 5 | 6: 0.146 | 0.146 |
+// 0.142; kernel 5: 0.156 | 0.169 | 0.163 at the identity, 0.176 | 0.183 | 0.180; kernel 6: 0.167 | 0.1645 | 0.170 at 3 deg + 2 %)
+constexpr int kChunkWgsPerCu[4] = {6, 0, 4, 5};
+template <typename K>
+unsigned chunk_grid(K kernel, int which, unsigned long long total_steps) {
+    struct PerDevice { int cus = 0, per_cu = 0; };
+    static PerDevice cache[4][64];  // by kernel and device; filled on first use (benign race: same values)
+    int dev = 0;
+    MIL_HIP(hipGetDevice(&dev));
+    PerDevice &pd = cache[which & 3][dev & 63];
+    if (pd.cus == 0) {
+        int cus = 0, per_cu = 0;
+        MIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        MIL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0));
+        pd.per_cu = std::max(per_cu, 1);
+        pd.cus = std::max(cus, 1);
+    }
+    int per_cu = std::min(pd.per_cu, kChunkWgsPerCu[which & 3]);
+    if (const char *e = getenv("MIL_CORR_CHUNK_WGS_PER_CU")) per_cu = std::max(1, atoi(e));  // experiments: read per call
+    const unsigned long long want = (unsigned long long)pd.cus * per_cu;
+    const unsigned long long most = (total_steps + kMinChunk - 1) / kMinChunk;
+    return (unsigned)std::max(1ull, std::min(want, most));
 }
 
 // The two-voxel kernels form their indices from the bit patterns of floor + 1.5 * 2^23 (corr_pair_kernel, prepare): the
@@ -795,6 +1095,42 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
         grid.z = (unsigned)((a.ty + kStepsZ - 1) / kStepsZ);
         if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "corr_sums: volume exceeds launch limits");
     }
+    const long long pitch = src.pitch;
+    if (layout != 0) {  // float2 volume [sz+2][sy+1][sx+2]
+        a.row4 = (int)(8 * xp);
+        a.plane4 = (int)(8 * xp * yp2);
+        a.origin4 = (int)(8 * ((yp2 + 1) * xp + 1));
+        a.bytes = (unsigned)(8 * xp * yp2 * zp);
+        a.origin4m = magic_origin(a.origin4, a.row4, a.plane4, 3);
+    } else {            // float volume [sz+2][sy+2][pitch]
+        a.row4 = (int)(4 * pitch);
+        a.plane4 = (int)(4 * pitch * yp);
+        a.origin4 = (int)(4 * (pitch * yp + pitch + 1));
+        a.bytes = (unsigned)(4 * pitch * yp * zp);
+        a.origin4m = magic_origin(a.origin4, a.row4, a.plane4, 2);
+    }
+    const float *volume = layout != 0 ? src.pairs.get() : src.data.get();
+    // (kernel 4 -- row pairs, both planes gathered every step -- needs 130 registers in this form and runs 4 x slower: tiled)
+    if (kernel >= 3 && kernel != 4 && use_chunks()) {
+        // columns of 128 (x) x 4 (the waves: y, or z when marching along y), walked along the marching axis
+        const int run_len = kernel == 6 ? a.ty : a.tz;
+        a.gx = a.tx / (2 * kTileX);
+        a.gy = ((kernel == 6 ? a.tz : a.ty) + kTileY - 1) / kTileY;
+        const unsigned long long total = (unsigned long long)a.gx * a.gy * run_len;
+        if (total > 0xffffffffull) throw Error(-1, "corr_sums: volume exceeds launch limits");
+        auto launch = [&](auto kern) {
+            const unsigned wgs = chunk_grid(kern, kernel - 3, total);
+            const CorrTail tail = ws.next(wgs, s);
+            hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), 0, s, target, volume, a, tail, (unsigned)total, run_len);
+        };
+        switch (kernel) {
+            case 3: launch(corr_chunk_kernel<false, true, false>); break;
+            case 5: launch(corr_chunk_kernel<true, true, false>); break;
+            default: launch(corr_chunk_kernel<false, true, true>); break;
+        }
+        MIL_HIP(hipGetLastError());
+        return;
+    }
     // the partials are those of the 64 x 4 x 16 decomposition whichever z-marching kernel runs (64 x 16 x 4 for kernel 6)
     const CorrTail tail = ws.next((size_t)grid.x * grid.y * grid.z, s);
     const int old_gx = (int)grid.x;
@@ -804,32 +1140,14 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
     const size_t n_wg = (size_t)grid.x * grid.y * grid.z;
     if (n_wg > 0x7fffffffu) throw Error(-1, "corr_sums: volume exceeds launch limits");
     grid = dim3((unsigned)n_wg);  // one-dimensional, decoded by corr_tile_of_block
-    if (layout != 0) {  // float2 volume [sz+2][sy+1][sx+2]
-        a.row4 = (int)(8 * xp);
-        a.plane4 = (int)(8 * xp * yp2);
-        a.origin4 = (int)(8 * ((yp2 + 1) * xp + 1));
-        a.bytes = (unsigned)(8 * xp * yp2 * zp);
-        const float *p = src.pairs.get();
-        a.origin4m = magic_origin(a.origin4, a.row4, a.plane4, 3);
-        switch (kernel) {
-            case 1: hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, p, a, tail); break;
-            case 2: hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, p, a, tail); break;
-            case 4: hipLaunchKernelGGL((corr_pair_kernel<true, false>), grid, dim3(kThreads), 0, s, target, p, a, tail, old_gx); break;
-            default: hipLaunchKernelGGL((corr_pair_kernel<true, true>), grid, dim3(kThreads), 0, s, target, p, a, tail, old_gx); break;
-        }
-    } else {            // float volume [sz+2][sy+2][pitch]
-        const long long pitch = src.pitch;
-        a.row4 = (int)(4 * pitch);
-        a.plane4 = (int)(4 * pitch * yp);
-        a.origin4 = (int)(4 * (pitch * yp + pitch + 1));
-        a.bytes = (unsigned)(4 * pitch * yp * zp);
-        a.origin4m = magic_origin(a.origin4, a.row4, a.plane4, 2);
-        if (kernel == 6)
-            hipLaunchKernelGGL((corr_pair_kernel<false, true, true>), grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail, old_gx);
-        else if (kernel == 3)
-            hipLaunchKernelGGL((corr_pair_kernel<false, true>), grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail, old_gx);
-        else
-            hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, src.data.get(), a, tail);
+    switch (kernel) {
+        case 0: hipLaunchKernelGGL(corr_padded_kernel, grid, dim3(kThreads), 0, s, target, volume, a, tail); break;
+        case 1: hipLaunchKernelGGL(corr_rowpair_kernel<false>, grid, dim3(kThreads), 0, s, target, volume, a, tail); break;
+        case 2: hipLaunchKernelGGL(corr_rowpair_kernel<true>, grid, dim3(kThreads), 0, s, target, volume, a, tail); break;
+        case 3: hipLaunchKernelGGL((corr_pair_kernel<false, true>), grid, dim3(kThreads), 0, s, target, volume, a, tail, old_gx); break;
+        case 4: hipLaunchKernelGGL((corr_pair_kernel<true, false>), grid, dim3(kThreads), 0, s, target, volume, a, tail, old_gx); break;
+        case 5: hipLaunchKernelGGL((corr_pair_kernel<true, true>), grid, dim3(kThreads), 0, s, target, volume, a, tail, old_gx); break;
+        default: hipLaunchKernelGGL((corr_pair_kernel<false, true, true>), grid, dim3(kThreads), 0, s, target, volume, a, tail, old_gx); break;
     }
     MIL_HIP(hipGetLastError());
 }

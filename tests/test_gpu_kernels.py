@@ -214,7 +214,7 @@ def test_padded_cost_kernel_is_bit_identical(dev):
     pad = dev.PaddedSource(src)
     for i, m in enumerate(g["mats"]):
         a = dev.corr_sums(tgt, src, m)
-        for kern in (-1, 0, 1, 2, 3, 4, 5, 6):  # per-matrix choice, then each padded-source kernel (3-6: two voxels per lane)
+        for kern in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):  # per-matrix choice, then each padded-source kernel (3-6: two voxels per lane)
             dev.corr_padded_force_kernel(kern)
             b = dev.corr_sums(tgt, pad, m)
             assert _same_sums(b, a, kern), f"golden matrix {i}, kernel {kern}: {b} vs {a}"
@@ -254,7 +254,7 @@ def test_padded_cost_kernel_is_bit_identical(dev):
         mats.append(np.full(12, np.nan, dtype=f32))
         for i, m in enumerate(mats):
             a = dev.corr_sums(dt, ds, m)
-            for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
+            for kern in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
                 dev.corr_padded_force_kernel(kern)
                 b = dev.corr_sums(dt, pad, m)
                 assert _same_sums(b, a, kern), f"{shape_s} matrix {i}, kernel {kern}: {b} vs {a}"

@@ -323,7 +323,7 @@ def test_full_size_cost_and_resample_vs_oracle_fixture(dev, api):
         wss, wst = g["corr_sums"][i]
         ss, st = dev.corr_sums(t_dev, s_dev, m)
         assert abs(ss - wss) <= 1e-12 * wss and abs(st - wst) <= 1e-12 * wss, (i, ss, st, wss, wst)
-        for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
+        for kern in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
             dev.corr_padded_force_kernel(kern)
             assert _same_sums(dev.corr_sums(t_dev, pad, m), (ss, st), kern), f"matrix {i}, padded kernel {kern}"
     dev.corr_padded_force_kernel(-1)
@@ -464,7 +464,7 @@ def test_full_size_registration_properties(dev):
     rot20[[3, 7]] = (90.0, -80.0)
     for m in (ident, rot, rot20):
         want = dev.corr_sums(ms, ms, m)
-        for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
+        for kern in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
             dev.corr_padded_force_kernel(kern)
             assert _same_sums(dev.corr_sums(ms, pad, m), want, kern), f"kernel {kern}"
     dev.corr_padded_force_kernel(-1)
@@ -566,7 +566,7 @@ def test_fenced_and_fence_free_tails_agree(dev, monkeypatch):
     c, s_ = np.cos(np.deg2rad(4.0)), np.sin(np.deg2rad(4.0))
     rot[[0, 2, 8, 10]] = np.array([c, -s_, s_, c], dtype=np.float32) * np.float32(0.98)
     rot[[3, 7, 11]] = (3.0, -2.0, 6.0)
-    for kern in (-1, 0, 1, 2, 3, 4, 5, 6):
+    for kern in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
         dev.corr_padded_force_kernel(kern)
         for m in (ident, rot):
             monkeypatch.delenv("MIL_CORR_FENCES", raising=False)
