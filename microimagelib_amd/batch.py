@@ -116,12 +116,15 @@ def gather_mip_stack(local: Dict[int, object], time_points: Sequence[int], mip_s
         return None
     out = {name: torch.empty((n,) + shp, dtype=torch.float32, device=device) for name, shp, _ in prods}
     index = {t: k for k, t in enumerate(time_points)}
+    del slab  # world > 1: rank 0's own contribution is parts[0] by now
     for r in range(world):
-        for i, t in enumerate(shard_time_points(time_points, r, world)):
+        part, parts[r] = parts[r], None  # each received slab is released as soon as its records are in place: rank 0 holds
+        for i, t in enumerate(shard_time_points(time_points, r, world)):  # the stacks + ONE slab, not the stacks twice
             off = 0
             for name, shp, c in prods:
-                out[name][index[t]].copy_(parts[r][i, off:off + c].reshape(shp))
+                out[name][index[t]].copy_(part[i, off:off + c].reshape(shp))
                 off += c
+        del part
     last_gather["seconds"] = time.perf_counter() - t0
     return out if isinstance(mip_shape, dict) else out[None]
 
@@ -215,16 +218,52 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
     token): by default the same group / device as the gather.  On the GPU node the driver passes a gloo group and "cpu", so
     that RCCL carries the gather of the projections and nothing else (north_star: "RCCL ... used only to gather the final MIP
     stack") and a 24-float token never waits behind a device-side point-to-point kernel.
-    Returns the time-ordered MIP stack on rank 0."""
+    Before the gather the ranks AGREE over the control group that all of them got there (`_agree`): a rank whose time point
+    raised reports it and every rank raises, instead of the healthy ones waiting in the gather for a peer that will never
+    come.  Returns the time-ordered MIP stack on rank 0."""
     rank, world = _world(group)
     time_points = list(time_points)
     if control_group is None:
         control_group = group
     if control_device is None:
         control_device = device if control_group is group else "cpu"
-    if policy.reg_mode == 2 and world > 1:
-        return _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group,
-                            control_group, control_device)
+    failure = None
+    local = None
+    try:
+        if policy.reg_mode == 2 and world > 1:
+            local = _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group,
+                                 control_group, control_device)
+        else:
+            local = _run_local(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, sink, device, group, overlap,
+                               lanes, control_group, control_device)
+    except Exception as e:  # reported to the peers first, raised below
+        failure = e
+    _agree(failure, control_group, control_device)
+    return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
+
+
+def _agree(failure, group, device):
+    """All ranks or none: MIN all-reduce of an "I am fine" flag over the control group (gloo on the GPU node: its timeout
+    turns a dead peer into an exception).  Raises this rank's own failure, or a RuntimeError naming the situation."""
+    rank, world = _world(group)
+    if world > 1:
+        flag = torch.tensor([0.0 if failure is not None else 1.0], dtype=torch.float32, device=device)
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        except Exception:
+            if failure is not None:
+                raise failure
+            raise
+        if failure is None and float(flag.item()) < 1.0:
+            raise RuntimeError("batch: another rank failed in its share of the time points; nothing was gathered")
+    if failure is not None:
+        raise failure
+
+
+def _run_local(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, sink, device, group, overlap, lanes,
+               control_group, control_device):
+    """run_sharded without the token ring: this rank's share, `local` = time point -> projections."""
+    rank, world = _world(group)
     if policy.reg_mode == 1:
         # register the test time point once (rank 0), then every rank applies that matrix (:719-751)
         tmx = None
@@ -279,7 +318,7 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
             concurrent.futures.wait(futures)
             for f in futures:
                 f.result()
-        return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
+        return local
 
     def finish(a, b_reg, t, tmx, rec):
         decon, mip = fuse_pair(a, b_reg, t)
@@ -320,7 +359,7 @@ def run_sharded(time_points: Sequence[int], load_pair: Callable[[int], Tuple[obj
         for ex in (worker, loader):
             if ex is not None:
                 ex.shutdown(wait=True)
-    return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
+    return local
 
 
 def _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mip_shape, sink, device, group,
@@ -360,7 +399,7 @@ def _run_chained(time_points, load_pair, fuse_pair, policy, reg_fn, check_fn, mi
             sink(t, decon, np.asarray(tmx, dtype=np.float32), np.asarray(rec, dtype=np.float32))
     for req, _ in sends:
         req.wait()
-    return gather_mip_stack(local, time_points, mip_shape, device=device, group=group)
+    return local
 
 
 # --------------------------------------------------------------------------- GPU pipeline (device-resident)

@@ -41,7 +41,7 @@ def hash_volume(shape, salt, structure_salt=12345):
     return (np.uint32(100) + noise + amp).astype(np.float32)
 
 
-def displaced_source(shape):
+def displaced_source(shape, noise_salt=3):
     """The registration source of the end-to-end fixture (config 4): view 3's noise on the shared brick structure, with
     the structure sampled at SHEARED and shifted integer coordinates
 
@@ -62,7 +62,7 @@ def displaced_source(shape):
                   ((zs >> np.uint32(3)) * np.uint32(83492791)) ^ np.uint32(12345))
     del xs, ys, zs
     amp = np.where((hb & np.uint32(7)) == 0, np.uint32(200) + ((hb >> np.uint32(3)) & np.uint32(1023)), np.uint32(0))
-    noise = _lattice(shape, 0, 0, 0, 3) & np.uint32(63)
+    noise = _lattice(shape, 0, 0, 0, noise_salt) & np.uint32(63)
     return (np.uint32(100) + noise + amp).astype(np.float32)
 
 
