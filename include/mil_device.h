@@ -62,6 +62,12 @@ int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, 
  * size3 = {width, height, projectNum}.  Synchronises `stream` before it returns. */
 int mil_mip3d(float *d_out, const float *d_img, int nx, int ny, int nz, int rAxis, long long projectNum, int *size3,
               void *stream);
+/* One angle of that series with the caller's matrix: the source resampled into a box of (bx, by, bz) by m12
+ * (affinetransformkernel, include/cukernel.cuh:501-524) and projected along the box's z (maxprojectionkernel :396-418,
+ * accumulator starting at 0) in ONE pass -- d_plane receives [by][bx] floats, the box itself is never written.  Bit-identical
+ * to mil_affine_resample + mil_max_projection(direction 1) on finite data. */
+int mil_resample_mip_z(float *d_plane, const float *d_src, int bx, int by, int bz, int sx, int sy, int sz, const float *m12,
+                       void *stream);
 
 /* ---- deconvolution engine -------------------------------------------------- */
 typedef struct mil_decon mil_decon;
@@ -130,17 +136,27 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
                          const float *m12, double *h_out, void *stream);
 /* test / profiling aid (process-wide): pin the padded-source kernel -- 0 plain layout + plane reuse, 1 row-pair layout,
  * 2 row-pair layout + plane reuse, 3 / 4 / 5 the same with two voxels per lane (target widths that are multiples of 128;
- * otherwise the one-voxel form runs), 6 plain layout, two voxels per lane, marching along y with row reuse; -1 (default)
- * chooses per matrix.  Kernels 0-5 return the same bits; kernel 6 sums the same voxel values in another order (equal to
- * ~1e-15 relative). */
+ * otherwise the one-voxel form runs), 6 plain layout, two voxels per lane, marching along y with row reuse; 7 / 9 / 10 the
+ * CHUNKED (persistent) forms of 3 / 5 / 6 -- the grid is what the device holds at once, one publish per workgroup -- which
+ * is what runs by default (8 is accepted and runs the tiled kernel 4; MIL_CORR_CHUNK=0 runs the tiled forms everywhere);
+ * -1 (default) chooses per matrix.  Kernels 0-5 return the same bits; kernels 6-10 sum the same float32 voxel values in
+ * another order (equal to ~1e-15 relative, bit-reproducible from run to run on one device). */
 int mil_corr_padded_force_kernel(int kernel);
 /* host logic only (no GPU needed): the LAYOUT the per-matrix choice takes for m12 -- 0 plain + plane reuse, 1 row pairs,
  * 2 row pairs + plane reuse (the one-voxel kernels; what runs when the target width is not a multiple of 128) */
 int mil_corr_padded_pick_kernel(const float *m12);
-/* the same choice as a KERNEL number (mil_corr_padded_force_kernel's numbering): wide != 0 for target widths that are
- * multiples of 128 -- 3 / 5 (two voxels per lane), 1 (row pairs, both planes gathered: one voxel per lane also there), or
- * 6 (march along y) where the re-gather rate along y is below 0.08 AND below half the rate along z; wide == 0: as above */
+/* the same choice as a KERNEL number (mil_corr_padded_force_kernel's numbering, tiled forms): wide != 0 for target widths
+ * that are multiples of 128 -- 3 / 5 (two voxels per lane), 1 (row pairs, both planes gathered: one voxel per lane also
+ * there), or 6 (march along y).  The thresholds are the constants kPlainMaxRate, kPairsReuseMaxRate, kMarchYMaxRate and
+ * kMarchYMaxSpread of csrc/corr_padded.hip (fitted on timed trajectory matrices, profiles/r04/reg_cost_pick.txt): kernel 6
+ * where the expected re-gather rate along y is below kMarchYMaxRate AND below the rate along z AND the 64 lanes of a wave
+ * stay within kMarchYMaxSpread source rows + planes; wide == 0: as above */
 int mil_corr_padded_pick_kernel2(const float *m12, int wide);
+/* host logic only: which kernel mil_affine_resample takes for an output of (ox, oy, oz) from a source of (sx, sy, sz) --
+ * 2 the marching kernel (csrc/resample_march.hip: two voxels per lane, plane / row reuse; sources below 2 GiB with planes
+ * below 2^22 voxels), 1 one voxel per thread with 32-bit offsets (planes below 2^24 voxels), 0 one voxel per thread with
+ * 64-bit address arithmetic (anything larger, sx < 2, or the texture-weight emulation).  All three return the same bits. */
+int mil_affine_resample_path(int ox, int oy, int oz, int sx, int sy, int sz);
 /* cost-kernel launches of this thread's last mil_reg3d_affine (records[5] counts evaluations like the reference; repeats of
  * a point just visited are answered from the last results, same value, no launch) */
 int mil_reg3d_last_cost_launches(void);

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mil_decon_timer_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mil_decon_timer_read": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
     "mil_affine_resample": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, C.c_void_p]),
+    "mil_affine_resample_path": (C.c_int, [C.c_int] * 6),
+    "mil_resample_mip_z": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, C.c_void_p]),
     "mil_corr_sums": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, c_double_p, C.c_void_p]),
     "mil_padded_source_eligible": (C.c_int, [C.c_int] * 6),
     "mil_reg3d_last_cost_launches": (C.c_int, []),

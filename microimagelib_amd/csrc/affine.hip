@@ -24,6 +24,7 @@
 
 #include "corr_finish.h"
 #include "kernels.h"
+#include "trilinear_dev.h"
 
 #include <cstdlib>
 
@@ -38,113 +39,7 @@ constexpr int kTileY = 4;    // 4 waves per workgroup
 constexpr int kCorrZ = 16;   // z-steps per thread in the cost kernel
 constexpr int kBlockThreads = kTileX * kTileY;
 
-struct AffineArgs {
-    float m[12];
-    int tx, ty, tz;  // target / output dims
-    int sx, sy, sz;  // source dims
-    float wq;        // 0: exact float32 weights; 256: weights rounded to 8 fractional bits (texture_weight_bits)
-};
-
-__device__ __forceinline__ float coord(const float *r, float ix, float iy, float iz) {
-    float t = r[0] * ix + r[1] * iy;  // d_aff[0]*ix + d_aff[1]*iy + d_aff[2]*iz + d_aff[3] + 0.5
-    t = t + r[2] * iz;
-    t = t + r[3];
-    return t + 0.5f;
-}
-
-struct Tap {
-    int i0, i1;
-    float w0, w1;
-};
-
-// wq > 0: CUDA-texture emulation.  The CUDA programming guide (texture fetching, linear filtering) stores the weight
-// "in 9-bit fixed point format with 8 bits of fractional value (so 1.0 is exactly represented)"; it does not say how it
-// rounds -- round to nearest is ASSUMED here -- nor how the filter arithmetic is carried out (ours stays
-// w0*q0 + w1*q1 in float32, x then y then z).  A comparison aid for volumes produced by the CUDA build, off by default.
-// QUANT = false: the caller knows wq == 0 (the compiler otherwise evaluates the quantised weight -- an IEEE division --
-// for every tap and selects: 3 divisions per voxel, a quarter of resample_kernel's instructions).
-template <bool QUANT = true>
-__device__ __forceinline__ Tap make_tap(float t, int n, float wq) {
-    float b = t - 0.5f;
-    float f = floorf(b);
-    Tap p;
-    p.w1 = b - f;
-    if (QUANT && wq > 0.0f) p.w1 = floorf(p.w1 * wq + 0.5f) / wq;
-    p.w0 = 1.0f - p.w1;
-    // Only called for t inside the validity window, so i = floor(t - 0.5) lies in [-1, n-1]: the edge clamp of the
-    // reference's texture fetch reduces to one max and one min.
-    const int i = (int)f;
-    p.i0 = i < 0 ? 0 : i;
-    p.i1 = i + 1 > n - 1 ? n - 1 : i + 1;
-    return p;
-}
-
-// The two x taps of a row are adjacent floats except where the clamp folds them onto one edge
-// voxel, so one 8-byte gather at b = clamp(i, 0, sx-2) serves both: half the texture-address work of two
-// 4-byte gathers (the cost kernel is bound by gather issue, not by HBM).  4-byte alignment only.
-struct __attribute__((packed, aligned(4))) Pair {
-    float lo, hi;
-};
-
-__device__ __forceinline__ float fetch_linear(const float *__restrict__ src, int sx, int sy, int sz, float tx, float ty,
-                                              float tz, float wq) {
-    Tap X = make_tap(tx, sx, wq), Y = make_tap(ty, sy, wq), Z = make_tap(tz, sz, wq);
-    const size_t row = (size_t)sx, plane = (size_t)sx * sy;
-    const float *p00 = src + Z.i0 * plane + Y.i0 * row;
-    const float *p01 = src + Z.i0 * plane + Y.i1 * row;
-    const float *p10 = src + Z.i1 * plane + Y.i0 * row;
-    const float *p11 = src + Z.i1 * plane + Y.i1 * row;
-    if (sx >= 2) {
-        const int b = X.i0 < sx - 2 ? X.i0 : sx - 2;  // X.i0 >= 0 already
-        const bool lo0 = X.i0 == b, lo1 = X.i1 == b;
-        const Pair q00 = *reinterpret_cast<const Pair *>(p00 + b), q01 = *reinterpret_cast<const Pair *>(p01 + b);
-        const Pair q10 = *reinterpret_cast<const Pair *>(p10 + b), q11 = *reinterpret_cast<const Pair *>(p11 + b);
-        float c00 = X.w0 * (lo0 ? q00.lo : q00.hi) + X.w1 * (lo1 ? q00.lo : q00.hi);
-        float c01 = X.w0 * (lo0 ? q01.lo : q01.hi) + X.w1 * (lo1 ? q01.lo : q01.hi);
-        float c10 = X.w0 * (lo0 ? q10.lo : q10.hi) + X.w1 * (lo1 ? q10.lo : q10.hi);
-        float c11 = X.w0 * (lo0 ? q11.lo : q11.hi) + X.w1 * (lo1 ? q11.lo : q11.hi);
-        float c0 = Y.w0 * c00 + Y.w1 * c01;
-        float c1 = Y.w0 * c10 + Y.w1 * c11;
-        return Z.w0 * c0 + Z.w1 * c1;
-    }
-    float c00 = X.w0 * p00[X.i0] + X.w1 * p00[X.i1];
-    float c01 = X.w0 * p01[X.i0] + X.w1 * p01[X.i1];
-    float c10 = X.w0 * p10[X.i0] + X.w1 * p10[X.i1];
-    float c11 = X.w0 * p11[X.i0] + X.w1 * p11[X.i1];
-    float c0 = Y.w0 * c00 + Y.w1 * c01;
-    float c1 = Y.w0 * c10 + Y.w1 * c11;
-    return Z.w0 * c0 + Z.w1 * c1;
-}
-
-// The same fetch for volumes below 2 GiB whose planes hold fewer than 2^24 voxels (every volume of this pipeline): ONE 32-bit
-// byte offset per tap row -- two 24-bit multiplies and adds instead of 64-bit multiply-adds per pointer -- through a buffer
-// descriptor.  Same taps, same float32 operations in the same order: the same bits.  (resample_kernel spent 195 vector
-// instructions per voxel, most of them address arithmetic: it was bound by them, not by its four gathers.)
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float fetch_linear_small(__amdgpu_buffer_rsrc_t rsrc, int sx, int sy, int sz, float tx, float ty,
-                                                    float tz, float wq) {
-    const Tap X = make_tap<false>(tx, sx, wq), Y = make_tap<false>(ty, sy, wq), Z = make_tap<false>(tz, sz, wq);  // wq == 0 (host check)
-    const int b = X.i0 < sx - 2 ? X.i0 : sx - 2;  // sx >= 2 (host check)
-    const bool lo0 = X.i0 == b, lo1 = X.i1 == b;
-    const unsigned plane = (unsigned)__mul24(sx, sy);
-    const unsigned z0 = (unsigned)__mul24(Z.i0, (int)plane), z1 = (unsigned)__mul24(Z.i1, (int)plane);
-    const unsigned y0 = (unsigned)__mul24(Y.i0, sx) + (unsigned)b, y1 = (unsigned)__mul24(Y.i1, sx) + (unsigned)b;
-    auto pair = [&](unsigned o) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(o << 2), 0, 0);
-        return Pair{__uint_as_float(v.x), __uint_as_float(v.y)};
-    };
-    const Pair q00 = pair(z0 + y0), q01 = pair(z0 + y1), q10 = pair(z1 + y0), q11 = pair(z1 + y1);
-    const float c00 = X.w0 * (lo0 ? q00.lo : q00.hi) + X.w1 * (lo1 ? q00.lo : q00.hi);
-    const float c01 = X.w0 * (lo0 ? q01.lo : q01.hi) + X.w1 * (lo1 ? q01.lo : q01.hi);
-    const float c10 = X.w0 * (lo0 ? q10.lo : q10.hi) + X.w1 * (lo1 ? q10.lo : q10.hi);
-    const float c11 = X.w0 * (lo0 ? q11.lo : q11.hi) + X.w1 * (lo1 ? q11.lo : q11.hi);
-    const float c0 = Y.w0 * c00 + Y.w1 * c01;
-    const float c1 = Y.w0 * c10 + Y.w1 * c11;
-    return Z.w0 * c0 + Z.w1 * c1;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t small_rsrc(const float *src, int sx, int sy, int sz) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, sx * sy * sz * 4, 0x00020000);
-}
+using namespace tri;
 
 // Plane cache of the cost kernel.  A lane walks z; for the near-axis-aligned matrices registration visits, the lower
 // source plane of step z+1 is the upper plane of step z (same row pair, same x pair), so its two 8-byte gathers were
@@ -321,14 +216,6 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
     corr_publish<kBlockThreads>(a0, a1, tail, lds, &last);
 }
 
-// fetch_linear_small applies: exact float32 weights (no texture-unit emulation), 32-bit byte offsets, 24-bit multiplies, 8-byte
-// pairs inside a row
-bool small_source(Dims s) {
-    static const bool off = getenv("MIL_RESAMPLE_SMALL") && getenv("MIL_RESAMPLE_SMALL")[0] == '0';
-    return !off && texture_weight_bits() == 0 && s.nx >= 2 && s.count() * 4 < (1ll << 31) && s.nx * s.ny < (1ll << 24) &&
-           s.nz < (1ll << 24);
-}
-
 AffineArgs make_args(Dims t, Dims s, const Affine12 &m) {
     if (t.nx <= 0 || t.ny <= 0 || t.nz <= 0 || s.nx <= 0 || s.ny <= 0 || s.nz <= 0)
         throw Error(-1, "affine kernel: empty volume");
@@ -347,6 +234,15 @@ std::atomic<int> g_weight_bits{-1};  // -1: not set through the API, MIL_TEX_WEI
 
 }  // namespace
 
+// fetch_linear_small applies: exact float32 weights (no texture-unit emulation), 32-bit byte offsets, UNSIGNED 24-bit multiplies
+// (planes below 2^24 voxels), 8-byte pairs inside a row.  MIL_RESAMPLE_SMALL=0 (read per call: the tests flip it) keeps the
+// 64-bit address arithmetic.
+bool small_source(Dims s) {
+    const char *e = getenv("MIL_RESAMPLE_SMALL");
+    return !(e && e[0] == '0') && texture_weight_bits() == 0 && s.nx >= 2 && s.count() * 4 < (1ll << 31) && s.nx * s.ny < (1ll << 24) &&
+           s.nz < (1ll << 24);
+}
+
 // 0 (default): exact float32 interpolation weights; 8: weights rounded to 8 fractional bits like the CUDA texture unit
 // the reference samples through (include/cukernel.cuh:510-522, 545-546) -- see make_tap.  Process-wide.
 int texture_weight_bits() {
@@ -362,6 +258,10 @@ void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims,
     AffineArgs a = make_args(out_dims, src_dims, m);
     dim3 grid((a.tx + kTileX - 1) / kTileX, (a.ty + kTileY - 1) / kTileY, a.tz);
     if (grid.y > 65535 || grid.z > 65535) throw Error(-1, "affine_resample: volume exceeds launch limits");
+    if (resample_march_eligible(out_dims, src_dims)) {  // two voxels per lane, marching with plane / row reuse
+        affine_resample_march(out, src, out_dims, src_dims, m, s, strict_window);
+        return;
+    }
     const bool small = small_source(src_dims);
     if (strict_window && small) hipLaunchKernelGGL((resample_kernel<true, true>), grid, dim3(kBlockThreads), 0, s, out, src, a);
     else if (strict_window) hipLaunchKernelGGL((resample_kernel<true, false>), grid, dim3(kBlockThreads), 0, s, out, src, a);
@@ -371,6 +271,10 @@ void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims,
 }
 
 void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s) {
+    if (resample_mip2_eligible(box, src_dims)) {  // taps under exact zero weights left out, z range clipped (resample_march.hip)
+        resample_mip2_z(out_plane, src, box, src_dims, m, s);
+        return;
+    }
     AffineArgs a = make_args(box, src_dims, m);
     // source rows / planes a wave's gather spreads over, with its 64 lanes along x or along z (see the kernel)
     const float along_x = 64.f * (fabsf(m.m[4]) + fabsf(m.m[8])), along_z = 64.f * (fabsf(m.m[6]) + fabsf(m.m[10]));

@@ -152,6 +152,16 @@ int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, 
     });
 }
 
+int mil_resample_mip_z(float *d_plane, const float *d_src, int bx, int by, int bz, int sx, int sy, int sz, const float *m12,
+                       void *stream) {
+    return guarded("mil_resample_mip_z", [&] {
+        k::Affine12 m;
+        std::memcpy(m.m, m12, sizeof m.m);
+        k::resample_mip_z(d_plane, d_src, dims3(bx, by, bz), dims3(sx, sy, sz), m, as_stream(stream));
+        return 0;
+    });
+}
+
 int mil_decon_create(mil_decon **out, int nx, int ny, int nz, void *stream) {
     return mil_decon_create_backend(out, nx, ny, nz, stream, MIL_BACKEND_AUTO);
 }
@@ -242,6 +252,11 @@ int mil_affine_resample(float *d_out, const float *d_src, int ox, int oy, int oz
         return 0;
     });
 }
+int mil_affine_resample_path(int ox, int oy, int oz, int sx, int sy, int sz) {
+    if (k::resample_march_eligible(dims3(ox, oy, oz), dims3(sx, sy, sz))) return 2;
+    return k::small_source(dims3(sx, sy, sz)) ? 1 : 0;
+}
+
 int mil_corr_sums(const float *d_target, const float *d_src, int tx, int ty, int tz, int sx, int sy, int sz,
                   const float *m12, double *h_out, void *stream) {
     return guarded("mil_corr_sums", [&] {

@@ -25,6 +25,9 @@
 // The 8-column tiles are dealt so that the two halves of a 128-byte row segment land on the same XCD (yz_conv, host side).
 // => {256, 512, 1024} x {1024, 512, 256, 128} x {64, 128, 256} (x, y, z) without ... x 1024 x 256, and ... x 128 x 512:
 // 36 boxes.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "fft2p.hip is written for gfx950 (v_permlane32_swap, 160 KB of LDS per workgroup): build with --offload-arch=gfx950"
+#endif
 #include "fftconv.h"
 
 #include <cstddef>
@@ -608,14 +611,20 @@ __device__ __forceinline__ void swap32(float2 &a, float2 &b) {
 
 // m / t: reciprocal, two Newton steps, v_div_fixup for the special cases -- the IEEE sequence without its range scaling
 // (6 instead of 10 instructions; 32 divisions per thread and trip were 13 % of the ratio kernel's arithmetic).  Within one
-// unit in the last place of the correctly rounded quotient for |t| in [2^-126, 2^126]; t = 0 gives +-inf like the
-// reference's unguarded division (div3Dkernel).
+// unit in the last place of the correctly rounded quotient for normal |t| below 2^126; outside that range (zero and
+// denormal denominators, where the reciprocal overflows and the Newton step would turn inf into NaN, or huge ones, whose
+// reciprocal flushes to zero) the lanes concerned take the IEEE division -- the quotient of the reference's unguarded
+// div3Dkernel, +-inf at t = 0 included.  Two compares per division; the branch is never taken on real data (T is N times
+// a positive estimate).
 __device__ __forceinline__ float xy_div(float m, float t) {
     float r = __builtin_amdgcn_rcpf(t);
     r = __builtin_fmaf(__builtin_fmaf(-t, r, 1.0f), r, r);
     float q = m * r;
     q = __builtin_fmaf(__builtin_fmaf(-t, q, m), r, q);
-    return __builtin_amdgcn_div_fixupf(q, t, m);
+    q = __builtin_amdgcn_div_fixupf(q, t, m);
+    constexpr int kNormal = 0x008 | 0x100;  // v_cmp_class: -normal | +normal
+    if (__builtin_expect(!(__builtin_amdgcn_classf(t, kNormal) && __builtin_fabsf(t) < 0x1p126f), 0)) q = m / t;
+    return q;
 }
 
 template <int MODE, int NY, int NH>

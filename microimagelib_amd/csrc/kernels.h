@@ -84,6 +84,13 @@ void set_texture_weight_bits(int bits);  // 0 | 8 | anything else: back to the e
 // strict_window: lower bound 0 < t instead of 0 <= t (the reference's 2-D transform kernel).
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m,
                      hipStream_t s, bool strict_window = false);
+// pieces of affine_resample (affine.hip, resample_march.hip)
+bool small_source(Dims src);  // fetch_linear_small's range: 32-bit offsets, planes below 2^24 voxels, exact float32 weights
+bool resample_march_eligible(Dims out, Dims src);
+void affine_resample_march(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s,
+                           bool strict_window);
+bool resample_mip2_eligible(Dims box, Dims src);
+void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s);
 // affine_resample into `box` followed by the maximum projection along z, fused: out_plane[box.ny][box.nx] (mip3dgpu's
 // inner pair, src/apifunc.cpp:610-613); same bits as the two kernels one after the other
 void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s);

@@ -115,6 +115,17 @@ def mip3d(a: torch.Tensor, r_axis: int, project_num: int, stream=None):
     return out
 
 
+def resample_mip_z(src: torch.Tensor, m12, box_shape, stream=None):
+    """One angle of the 3-D MIP series with the caller's matrix: resample into a box (nz, ny, nx) and project along its z, fused;
+    returns the [ny][nx] plane."""
+    m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)
+    bz, by, bx = (int(v) for v in box_shape)
+    out = torch.empty((by, bx), dtype=torch.float32, device=src.device)
+    _check(_lib.load().mil_resample_mip_z(_ptr(out), _ptr(src), bx, by, bz, *_dims(src), m.ctypes.data_as(_lib.c_float_p),
+                                          _stream_ptr(stream)), "mil_resample_mip_z")
+    return out
+
+
 def affine_resample(src: torch.Tensor, m12, out_shape, stream=None):
     out = torch.empty(tuple(out_shape), dtype=torch.float32, device=src.device)
     m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)

@@ -280,6 +280,73 @@ def test_affine_identity_is_exact_copy(dev):
     assert torch.equal(dev.affine_resample(x, ident, x.shape), x)
 
 
+def test_marching_resample_equals_the_one_voxel_kernel(dev, monkeypatch):
+    """affine_resample runs as a marching kernel (csrc/resample_march.hip: two voxels per lane, plane / row reuse, clamps
+    only on the rim); MIL_RESAMPLE_MARCH=0 keeps the one-voxel kernel of csrc/affine.hip.  Same bits -- interior, rim, out of
+    the window, ragged widths (lanes beyond the row), both marching axes, outputs smaller and larger than the source, a
+    one-plane source (never off the rim), large rotations."""
+    import torch
+    rng = np.random.default_rng(5)
+    ident = np.eye(3, 4, dtype=f32).reshape(12)
+
+    def rot(axis, deg, scale=1.0, shift=(0, 0, 0), shape=(40, 70, 130)):
+        c, s_ = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
+        r = {"y": [[c, 0, -s_], [0, 1, 0], [s_, 0, c]], "x": [[1, 0, 0], [0, c, -s_], [0, s_, c]], "z": [[c, -s_, 0], [s_, c, 0], [0, 0, 1]]}[axis]
+        lin = scale * np.array(r)
+        ctr = np.array([shape[2] / 2, shape[1] / 2, shape[0] / 2])
+        return np.concatenate([lin, (ctr - lin @ ctr + np.array(shift))[:, None]], axis=1).astype(f32).reshape(12)
+    cases = []
+    for s_shape, o_shape in (((40, 70, 130), (40, 70, 130)), ((40, 70, 130), (37, 45, 300)), ((17, 23, 70), (19, 21, 66)),
+                             ((33, 40, 256), (33, 40, 256)), ((1, 50, 90), (4, 50, 90)), ((9, 2, 2), (9, 5, 7)),
+                             ((48, 64, 128), (64, 16, 128))):
+        mats = [ident, rot("y", 3, 1.02, (5, -3, 2), s_shape), rot("y", 2, 1.0, (0.5, 0, -0.5), s_shape),
+                rot("x", 2, 0.99, (3, -2, 1), s_shape), rot("z", 7, 1.0, (0, 0, 0), s_shape), rot("y", 45, 1.0, (0, 0, 0), s_shape),
+                rot("x", 90, 1.0, (0, 0, 0), s_shape)]
+        for d in (-0.5, 0.5, -1.0, 0.25):
+            m = ident.copy()
+            m[[3, 7, 11]] = d
+            mats.append(m)
+        for k in range(3):
+            m = ident + rng.normal(0, 0.05 * (k + 1), 12).astype(f32)
+            m[[3, 7, 11]] = rng.uniform(-4, 4, 3).astype(f32)
+            mats.append(m)
+        mats.append(np.full(12, np.nan, dtype=f32))
+        mats.append(ident * f32(0))
+        src = T(rng.standard_normal(s_shape).astype(f32))
+        for i, m in enumerate(mats):
+            monkeypatch.setenv("MIL_RESAMPLE_MARCH", "0")
+            want = dev.affine_resample(src, m, o_shape)
+            monkeypatch.delenv("MIL_RESAMPLE_MARCH")
+            got = dev.affine_resample(src, m, o_shape)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (s_shape, o_shape, i)
+            cases.append(1)
+    assert len(cases) > 80
+
+
+def test_resample_of_planes_beyond_2_to_23_voxels(dev, monkeypatch):
+    """fetch_linear_small forms its offsets with UNSIGNED 24-bit multiplies: a source whose planes hold 2^23 .. 2^24 voxels
+    (4096 x 2048) must resample exactly like the 64-bit address path (MIL_RESAMPLE_SMALL=0) -- the signed multiply read such
+    a plane pitch as negative and every tap above plane 0 fell outside the buffer (zeros)."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(3)
+    src = torch.rand((3, 2048, 4096), device="cuda", generator=g) + 1.0
+    m = np.eye(3, 4, dtype=f32).reshape(12)
+    m[[3, 7, 11]] = (0.25, -0.5, 0.75)
+    m[1], m[4] = 0.001, -0.001
+    out_shape = (3, 256, 4096)
+    monkeypatch.setenv("MIL_RESAMPLE_MARCH", "0")
+    small = dev.affine_resample(src, m, out_shape)
+    monkeypatch.setenv("MIL_RESAMPLE_SMALL", "0")
+    wide = dev.affine_resample(src, m, out_shape)
+    assert torch.equal(small.view(torch.int32), wide.view(torch.int32))
+    assert float(small[1, 8:-8, 8:-8].min()) > 0.5  # plane 1 (taps in source planes 1 and 2) holds data, not the zeros of an
+    #                                                 out-of-range load; plane 2 maps beyond the source (tz = 3.25)
+    monkeypatch.delenv("MIL_RESAMPLE_SMALL")
+    monkeypatch.delenv("MIL_RESAMPLE_MARCH")
+    mip_a = dev.mip3d(src[:, :64, :256].contiguous(), 2, 4)
+    assert torch.isfinite(mip_a).all()
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_affine_random_matrices_vs_oracle(dev, seed):
     rng = np.random.default_rng(100 + seed)

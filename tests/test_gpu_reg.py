@@ -208,6 +208,49 @@ def test_fused_mip3d_equals_the_two_kernel_sequence(api, monkeypatch):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"axis {axis}"
 
 
+def test_fused_resample_projection_kernels_agree(monkeypatch):
+    """resample_mip_z in its three forms -- second version (csrc/resample_march.hip: taps under exact zero weights left out for
+    the rotation series' matrices, z range clipped per wave), first version (MIL_MIP3D_V2=0) and the two-kernel sequence
+    affine_resample + max_projection -- on rotation-series matrices about x and y, general matrices (no tap can be left out:
+    only the clipping applies), shifts that put a whole face outside, and a matrix that maps everything outside."""
+    import torch
+    from microimagelib_amd import device as dev
+    rng = np.random.default_rng(8)
+    vol = (do.blob_volume((40, 70, 90), n_blobs=25, seed=9) - f32(60.0)).astype(np.float32)
+    vol += rng.standard_normal(vol.shape).astype(np.float32)
+    src = torch.from_numpy(vol).cuda()
+    sz, sy, sx = vol.shape
+    cases = []
+    for axis in (1, 2):
+        rot = int(round(np.sqrt(float((sy if axis == 1 else sx) ** 2 + sz * sz))))
+        box = (rot, rot, sx) if axis == 1 else (rot, sy, rot)
+        for deg in (0, 10, 40, 90, 130, 180, 270, 350):
+            cases.append((ro.rot2matrix(f32(np.deg2rad(deg)), sx, sy, sz, axis), box))
+    ident = np.eye(3, 4, dtype=f32).reshape(12)
+    for k in range(6):
+        m = ident + rng.normal(0, 0.1 * (k + 1), 12).astype(f32)
+        m[[3, 7, 11]] = rng.uniform(-20, 20, 3).astype(f32)
+        cases.append((m, (50, 64, 100)))
+    far = ident.copy()
+    far[[3, 7, 11]] = (500.0, 0.0, 0.0)
+    cases.append((far, (40, 70, 90)))
+    half = ident.copy()
+    half[[3, 7, 11]] = (0.5, -30.0, 0.25)  # x row (1, 0, 0, 0.5): NOT an integer shift, no tap may be dropped
+    cases.append((half, (40, 70, 90)))
+    flat = ident.copy()
+    flat[10] = 0.0  # every z of the box on one source plane
+    flat[11] = 7.25
+    cases.append((flat, (33, 70, 90)))
+    for i, (m, box) in enumerate(cases):
+        want = dev.max_projection(dev.affine_resample(src, m, box), 1)
+        got = dev.resample_mip_z(src, m, box)
+        monkeypatch.setenv("MIL_MIP3D_V2", "0")
+        old = dev.resample_mip_z(src, m, box)
+        monkeypatch.delenv("MIL_MIP3D_V2")
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"case {i}: second version"
+        assert torch.equal(old.view(torch.int32), want.view(torch.int32)), f"case {i}: first version"
+
+
 # ---------------------------------------------------------------- regChoice 4: 2-D MIP shift search
 def _shifted_pair(shape=(24, 40, 48), shift=(3.0, -2.0, 1.6)):
     tgt = do.blob_volume(shape, n_blobs=15, seed=3)

@@ -145,3 +145,22 @@ def test_cost_kernel_choice_per_matrix(lib):
     assert pick2(rot_y(20.0)) == 1 and pick2(rot_y(45.0)) == 1  # large: row pairs, both planes, one voxel per lane
     for m in (ident, rot_y(3.0, 1.02), rot_x(5.0), rot_y(20.0)):
         assert pick2(m, wide=0) == pick(m)                      # narrow targets: the one-voxel kernel of that layout
+
+
+def test_resample_kernel_gate():
+    """Which kernel affine_resample takes (csrc/affine.hip small_source, csrc/resample_march.hip) -- host logic, no GPU.
+    32-bit offsets with UNSIGNED 24-bit multiplies hold for planes below 2^24 voxels and sources below 2 GiB; the marching
+    kernel additionally needs the plane pitch in BYTES below 2^24."""
+    from microimagelib_amd import _lib
+    lib = _lib.load()
+    path = lambda o, s: lib.mil_affine_resample_path(o[0], o[1], o[2], s[0], s[1], s[2])
+    assert path((512, 512, 256), (512, 512, 256)) == 2
+    assert path((572, 512, 572), (512, 512, 256)) == 2           # a rotated box larger than the source
+    assert path((64, 64, 2), (2048, 2047, 2)) == 2               # plane pitch just below 2^24 bytes
+    assert path((64, 64, 2), (2048, 2048, 2)) == 1               # at 2^24 bytes: one voxel per thread, 32-bit offsets
+    assert path((64, 64, 2), (4096, 2048, 2)) == 1               # 2^23 voxels per plane (the signed multiply's trap)
+    assert path((64, 64, 2), (4096, 4095, 2)) == 1               # just below 2^24 voxels per plane
+    assert path((64, 64, 2), (4096, 4096, 2)) == 0               # 2^24 voxels per plane: 64-bit arithmetic
+    assert path((64, 64, 64), (1024, 1024, 512)) == 0            # 2 GiB
+    assert path((64, 64, 64), (1, 64, 64)) == 0                  # no x pair to gather
+    assert path((1024, 1024, 1024), (64, 64, 64)) == 1           # output offsets beyond 32 bits: not the marching kernel

@@ -293,3 +293,66 @@ def test_itrilerp2_weights(ref):
         bx, by, bz = f32(f32(dx1 + h) - h), f32(f32(dy1 + h) - h), f32(f32(dz1 + h) - h)
         want = ref.ref_itrilerp2(bx, f32(1) - bx, by, f32(1) - by, bz, f32(1) - bz, P(q))
         assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32)
+
+
+# ------------------------------------------------------------------ a20: checkmatrix, compiled from src/api_reg.cpp:246-262
+def test_checkmatrix_oracle_and_product_against_the_compiled_reference():
+    """checkmatrix decides the batch's fall-back ladder (src/spim_fusion_batch.cpp:730-746).  The reference's own function
+    (oracle/_ref/libregcheck_ref.so: src/api_reg.cpp:246-262 cut out by line range, `make -C oracle regcheck`) against the
+    oracle's restatement AND libapi.so's checkmatrix on 10 000 random matrices plus every threshold and its float32
+    neighbours on both sides (scale bounds 0.5 / 1.4, scale-sum bounds 2 / 4, shift bound 0.8 * extent), NaN and inf."""
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libregcheck_ref.so")
+    if not os.path.exists(lib_path):
+        if not os.path.isdir("/root/reference"):
+            pytest.skip("oracle/_ref/libregcheck_ref.so needs the reference tree at build time")
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "regcheck"])
+    ref = C.CDLL(lib_path)
+    ref.ref_checkmatrix.argtypes = [fp, LL, LL, LL]
+    from microimagelib_amd import api
+    rng = np.random.default_rng(20)
+    dims = [(512, 512, 256), (100, 37, 5), (1, 1, 1), (3000, 2, 700)]
+    mats = []
+    for _ in range(10000):
+        m = rng.normal(0, 0.3, 12).astype(f32)
+        m[[0, 5, 10]] = rng.uniform(0.3, 1.7, 3).astype(f32)
+        m[[3, 7, 11]] = (rng.uniform(-1.2, 1.2, 3) * np.array(dims[len(mats) % 4])).astype(f32)
+        mats.append(m)
+    ident = np.eye(3, 4, dtype=f32).reshape(12)
+
+    def near(v):
+        v = f32(v)
+        return [np.nextafter(v, f32(-np.inf)), v, np.nextafter(v, f32(np.inf))]
+    for idx in (0, 5, 10):
+        for bound in (0.5, 1.4):
+            for v in near(bound):
+                m = ident.copy()
+                m[idx] = v
+                mats.append(m)
+    for total in (2.0, 4.0):  # the float32 sum (m0 + m5) + m10 at the bounds: 2 = 0.5 + 0.5 + 1, 4 = 1.4 + 1.3 + 1.3 ...
+        for v in near(total - 1.4 - 0.6 if total == 2.0 else total - 1.4 - 1.4):
+            m = ident.copy()
+            m[[0, 5]] = (1.4, 0.6) if total == 2.0 else (1.4, 1.4)
+            m[10] = v
+            mats.append(m)
+    for idx, axis in ((3, 0), (7, 1), (11, 2)):
+        for d in dims:
+            for sign in (1.0, -1.0):
+                for v in near(f32(0.8) * f32(d[axis])):
+                    m = ident.copy()
+                    m[idx] = f32(sign) * v
+                    mats.append(m)
+    for bad in (np.nan, np.inf, -np.inf):
+        for idx in (0, 3, 10, 11):
+            m = ident.copy()
+            m[idx] = bad
+            mats.append(m)
+    n_true = 0
+    for i, m in enumerate(mats):
+        m = np.ascontiguousarray(m, dtype=f32)
+        for sx, sy, sz in (dims if i >= 10000 else [dims[i % 4]]):
+            want = bool(ref.ref_checkmatrix(P(m), sx, sy, sz))
+            assert ro.checkmatrix(m, sx, sy, sz) == want, (i, m, (sx, sy, sz), "oracle")
+            assert api.checkmatrix(m, sx, sy, sz) == want, (i, m, (sx, sy, sz), "libapi.so")
+            n_true += want
+    assert 500 < n_true < len(mats) * 4  # both outcomes are exercised

@@ -10,7 +10,7 @@ base="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-fast-math -Wall -Wno-unuse
 case $src in
   fft2p.hip) fl="$base -ffp-contract=fast -fno-slp-vectorize" ;;
   fft.hip) fl="$base -ffp-contract=fast" ;;
-  corr_padded.hip) fl="$base -fvisibility-inlines-hidden -ffp-contract=off -fno-slp-vectorize -mllvm -disable-vector-combine" ;;
+  corr_padded.hip|resample_march.hip) fl="$base -fvisibility-inlines-hidden -ffp-contract=off -fno-slp-vectorize -mllvm -disable-vector-combine" ;;
   *) fl="$base -fvisibility-inlines-hidden -ffp-contract=off" ;;
 esac
 /opt/rocm/bin/hipcc $fl "$@" -c $cs/$src -o $out/$name.$src.o
