@@ -57,15 +57,34 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
+// AUX: the cache-policy bits of the access (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt marks a stream -- data written
+// or read once by this kernel and next touched, from HBM anyway, by the following one (a spectrum is 268 MB).
+#ifndef MIL_AUX_ST_SPEC
+#define MIL_AUX_ST_SPEC 0
+#endif
+#ifndef MIL_AUX_ST_REAL
+#define MIL_AUX_ST_REAL 0
+#endif
+#ifndef MIL_AUX_LD_SPEC
+#define MIL_AUX_LD_SPEC 0
+#endif
+#ifndef MIL_AUX_LD_REAL
+#define MIL_AUX_LD_REAL 0
+#endif
+#ifndef MIL_AUX_LD_OTF
+#define MIL_AUX_LD_OTF 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX);
     return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 x) {
     u32x2 v;
     v.x = __float_as_uint(x.x);
     v.y = __float_as_uint(x.y);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, AUX);
 }
 // Twiddles of the in-register stages: their index is uniform over a wave, and from constant memory that is a scalar
 // load into SGPRs (through a kernel argument the compiler cannot prove the table read-only and fetches every twiddle
@@ -277,11 +296,11 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc)
-                    o[q & 1][kc * 4 + k] = buf_load2(ro, ovoff, ooff0 + (unsigned)((k * kGroups * kNZ + 64 * q + kc) * kW) * 8u);
+                    o[q & 1][kc * 4 + k] = buf_load2<MIL_AUX_LD_OTF>(ro, ovoff, ooff0 + (unsigned)((k * kGroups * kNZ + 64 * q + kc) * kW) * 8u);
         };
         MIL_STAMP(0);
 #pragma unroll
-        for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * zstep);
+        for (int m = 0; m < 64; ++m) v[m] = buf_load2<MIL_AUX_LD_SPEC>(rs, voff, soff0 + m * zstep);
         load_otf(0);
         load_otf(1);
         // ---- z forward, stages L = 256 (over j1) and L = 32 (over j2), in registers
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
         MIL_STAMP(4);
         if (g != 0 || col != 0) {  // the packed column belongs to the pair blocks below
 #pragma unroll
-            for (int m = 0; m < 64; ++m) buf_store2(rs, voff, soff0 + m * zstep, v[m]);
+            for (int m = 0; m < 64; ++m) buf_store2<MIL_AUX_ST_SPEC>(rs, voff, soff0 + m * zstep, v[m]);
         }
         MIL_STAMP(5);
 #ifdef MIL_FX_STAMPS
@@ -680,7 +699,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
     const float2 wf = a.tw_x[kc];
     const float fc1 = odd ? -wf.x : wf.x, fc2 = wf.y, fh1 = 0.5f * fc1, fh2 = 0.5f * fc2;
 #pragma unroll
-    for (int m = 0; m < 64; ++m) v[m] = buf_load2(rs, voff, soff0 + m * rstep);
+    for (int m = 0; m < 64; ++m) v[m] = buf_load2<MIL_AUX_LD_SPEC>(rs, voff, soff0 + m * rstep);
     // ---- y inverse head: DIT stages L = NY / 8 (over j2, m = j2 + 8 j1; element i = n2 of its sub-transform) and L = NY
     // (over j1; element i = n2 + T j2)
 #pragma unroll
@@ -733,7 +752,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
         }
         // M / E of the first pass of the fused stage: in flight during the LDS stage (v[0..15] are free now)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pre[r] = buf_load2(rr, svoff, rsoff + r * srj);
+        for (int r = 0; r < 8; ++r) pre[r] = buf_load2<MIL_AUX_LD_REAL>(rr, svoff, rsoff + r * srj);
         if (grp == 0) MIL_STAMP(8);
         lds_barrier();
         if (grp == 0) MIL_STAMP(9);
@@ -755,7 +774,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
             for (int r = 0; r < 8; ++r) mm[r] = pre[8 * ps + r];
             if (ps == 0) {  // the second pass's M / E
 #pragma unroll
-                for (int r = 0; r < 8; ++r) pre[8 + r] = buf_load2(rr, svoff, rsoff + spass + r * srj);
+                for (int r = 0; r < 8; ++r) pre[8 + r] = buf_load2<MIL_AUX_LD_REAL>(rr, svoff, rsoff + spass + r * srj);
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) t[c] = p[c * SCS];
@@ -781,7 +800,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
                     float2 e = make_float2(m.x * t[j].x, m.y * t[j].y);
                     e.x = (e.x > a.eps) ? e.x : a.eps;
                     e.y = (e.y > a.eps) ? e.y : a.eps;
-                    buf_store2(rr, svoff, rsoff + ps * spass + j * srj, e);
+                    buf_store2<MIL_AUX_ST_REAL>(rr, svoff, rsoff + ps * spass + j * srj, e);
                     t[j] = e;
                 }
             }
@@ -866,7 +885,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
     }
     MIL_STAMP(4);
 #pragma unroll
-    for (int m = 0; m < 64; ++m) buf_store2(rs, voff, soff0 + m * rstep, v[m]);
+    for (int m = 0; m < 64; ++m) buf_store2<MIL_AUX_ST_SPEC>(rs, voff, soff0 + m * rstep, v[m]);
     MIL_STAMP(5);
 #ifdef MIL_FX_STAMPS
     if (a.stamps) {
