@@ -69,6 +69,43 @@ int mil_mip3d(float *d_out, const float *d_img, int nx, int ny, int nz, int rAxi
 int mil_resample_mip_z(float *d_plane, const float *d_src, int bx, int by, int bz, int sx, int sy, int sz, const float *m12,
                        void *stream);
 
+/* ---- whole stages on device-resident volumes ----------------------------------
+ * The libapi.h calls without their two PCIe trips, for hosts that keep a time point in HBM from the TIFF reader to the TIFF
+ * writer (cli/spim_fusion_batch_main.cpp).  Same kernels in the same order as the host-pointer entries: the same bits. */
+/* device / pinned host memory, streams and transfers, so that such a host needs no HIP header (sizes in bytes) */
+int mil_dev_alloc(void **d_ptr, size_t bytes);     /* from the library's per-device pool */
+void mil_dev_free(void *d_ptr);
+int mil_host_alloc(void **h_ptr, size_t bytes);    /* pinned */
+void mil_host_free(void *h_ptr);
+int mil_stream_create(void **stream);              /* non-blocking */
+void mil_stream_destroy(void *stream);
+int mil_stream_sync(void *stream);
+int mil_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);     /* asynchronous on `stream` */
+int mil_download(void *h_dst, const void *d_src, size_t bytes, void *stream);
+/* 16-bit stacks: readtifstack's widening (float)v (src/apifunc.cpp:166-183) and writetifstack's C cast (unsigned short)f
+ * (:255: truncation toward zero, low 16 bits; values no long long holds, and NaN, give 0) -- on the device, so that 16-bit
+ * files cross PCIe as 16 bits */
+int mil_u16_to_f32(float *d_out, const unsigned short *d_in, size_t n, void *stream);
+int mil_f32_to_u16(unsigned short *d_out, const float *d_in, size_t n, void *stream);
+/* imresize3d (src/apifunc.cpp:429-446): output (sx, sy, sz) from input (sx2, sy2, sz2) */
+int mil_imresize3d(float *d_out, const float *d_in, long long sx, long long sy, long long sz, long long sx2, long long sy2,
+                   long long sz2, void *stream);
+/* reg3d (src/api_reg.cpp:264-607; libapi.h:29-31) without gpuMemMode / deviceNum: all five regChoice paths, the centred
+ * align of a differently sized source, records[11] as there.  d_reg (imSize1 floats) must not overlap the inputs.  Returns
+ * when d_reg is complete. */
+int mil_reg3d(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, const unsigned int *imSize1,
+              const unsigned int *imSize2, int regChoice, int affMethod, int flagTmx, float FTOL, int itLimit, int verbose,
+              float *records, void *stream);
+/* decon_singleview / decon_dualview (src/api_decon.cpp:53-331, 333-704; libapi.h:42-46), GPU mode: images and result are
+ * device pointers of imSize floats (the images are only read), the PSFs host pointers; the cached engine (per device and FFT
+ * box) runs on its own stream ordered after `stream`; returns when d_decon is complete.  deconRecords[10] as there. */
+int mil_decon_singleview(float *d_decon, const float *d_img, const unsigned int *imSize, const float *h_psf,
+                         const unsigned int *psfSize, int flagConstInitial, int itNumForDecon, int verbose, float *deconRecords,
+                         int flagUnmatch, const float *h_psf_bp, void *stream);
+int mil_decon_dualview(float *d_decon, const float *d_img1, const float *d_img2, const unsigned int *imSize, const float *h_psf1,
+                       const float *h_psf2, const unsigned int *psfSize, int flagConstInitial, int itNumForDecon, int verbose,
+                       float *deconRecords, int flagUnmatch, const float *h_psf_bp1, const float *h_psf_bp2, void *stream);
+
 /* ---- deconvolution engine -------------------------------------------------- */
 typedef struct mil_decon mil_decon;
 /* Transform backends of the engine.  FUSED: hand-written LDS-tiled transforms with the OTF

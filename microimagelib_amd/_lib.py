@@ -90,6 +90,25 @@ SIGNATURES = {
     "mil_decon_timer_read": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
     "mil_affine_resample": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, C.c_void_p]),
     "mil_affine_resample_path": (C.c_int, [C.c_int] * 6),
+    "mil_dev_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "mil_dev_free": (None, [C.c_void_p]),
+    "mil_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "mil_host_free": (None, [C.c_void_p]),
+    "mil_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "mil_stream_destroy": (None, [C.c_void_p]),
+    "mil_stream_sync": (C.c_int, [C.c_void_p]),
+    "mil_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mil_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mil_u16_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mil_f32_to_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mil_imresize3d": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_longlong] * 6 + [C.c_void_p]),
+    "mil_reg3d": (C.c_int, [C.c_void_p, c_float_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int, C.c_int,
+                            C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, C.c_void_p]),
+    "mil_decon_singleview": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint), c_float_p, C.POINTER(C.c_uint), C.c_int, C.c_int,
+                                       C.c_int, c_float_p, C.c_int, c_float_p, C.c_void_p]),
+    "mil_decon_dualview": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint), c_float_p, c_float_p,
+                                     C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, c_float_p, c_float_p,
+                                     C.c_void_p]),
     "mil_resample_mip_z": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, C.c_void_p]),
     "mil_corr_sums": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_float_p, c_double_p, C.c_void_p]),
     "mil_padded_source_eligible": (C.c_int, [C.c_int] * 6),

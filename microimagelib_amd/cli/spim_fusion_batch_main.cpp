@@ -14,7 +14,17 @@
 //                   time point i-1 to the worker of i, which has its stacks loaded and preprocessed by then; it registers,
 //                   hands the state on and only then deconvolves.
 // Results, file names and matrix files are those of the single-device run bit for bit; ProcessingLog.txt is written in
-// time-point order whichever worker finishes first.  A device may be listed twice ("0,0"): two workers then share it.
+// time-point order whichever worker finishes first.  A device may be listed twice ("0,0"): two workers then share it --
+// which is also what a single device number gets by default (MIL_BATCH_WORKERS_PER_DEVICE=1: one worker, the reference's
+// strictly sequential order).
+//
+// A time point stays in HBM from the TIFF reader to the TIFF writer (round 5): the stacks are uploaded once -- 16-bit files
+// as 16 bits, widened to float on the device -- and resize / rotate, registration, deconvolution and the projections run on
+// device pointers (include/mil_device.h: mil_imresize3d, mil_rot_y90, mil_reg3d, mil_decon_dualview, mil_max_projection,
+// mil_mip3d); what comes back is what is written: the deconvolved stack (as 16 bits when that is the output depth), the
+// projections, the matrix.  The host-pointer path of round 4 -- the calls the reference's main makes, ~10 PCIe trips of
+// 268 MB per time point -- is kept behind MIL_BATCH_PATH=host for comparisons.  Same kernels in the same order: every output
+// file is the host-pointer path's (and the reference main's) byte for byte (tests/test_gpu_cli.py).
 //
 // Unlike the reference the file I/O does not sit in the GPU's way: each worker reads (and converts to float) its next time
 // point's two stacks on a helper thread while this one is registered and deconvolved, and writes the deconvolved stack
@@ -35,6 +45,7 @@
 #include <utility>
 
 #include "cli_common.h"
+#include "../../include/mil_device.h"
 
 namespace {
 
@@ -148,6 +159,15 @@ std::vector<int> parse_devices(const char *arg34) {
         pos = comma + 1;
     }
     if (out.empty()) out.push_back(atoi(arg34));
+    // One device named once: TWO workers share it unless MIL_BATCH_WORKERS_PER_DEVICE=1 says otherwise.  A registration is a
+    // chain of ~2 000 dependent cost evaluations with a host round trip between any two, and the readers / writers sit
+    // between the GPU stages of a time point: a second time point in flight fills those gaps (2.76 -> 2.90 time points/s at
+    // 512 x 512 x 256, profiles/r05/bench_cli_batch.json).  Results do not depend on the number of workers.
+    if (out.size() == 1) {
+        const char *per = getenv("MIL_BATCH_WORKERS_PER_DEVICE");
+        const int n = per ? atoi(per) : 2;
+        for (int i = 1; i < n && i < 8; ++i) out.push_back(out[0]);
+    }
     return out;
 }
 
@@ -310,27 +330,30 @@ int main(int argc, char **argv) {
         }
         return true;
     };
-    // One registration attempt / the ladder, on device `dev`, into b_reg; st.tmx in / out.
-    auto run_reg = [&](RegState &st, Prepared &p, std::vector<float> &b_reg, float *rec, int choice, bool use_input, int dev) {
-        return reg3d(b_reg.data(), st.tmx, p.a->data.data(), p.b->data.data(), p.a->size, p.b->size, choice, aff_method, use_input,
-                     ftol, it_limit, dev, -1, true, rec);
+    // One registration attempt = reg(tmx in / out, rec, regChoice, use the input matrix) -> status; the ladder around it.
+    typedef std::function<int(float *, float *, int, bool)> RegCall;
+    auto host_reg = [&](Prepared &p, std::vector<float> &b_reg, int dev) -> RegCall {
+        return [&p, &b_reg, dev, aff_method, ftol, it_limit](float *tmx, float *rec, int choice, bool use_input) {
+            return reg3d(b_reg.data(), tmx, p.a->data.data(), p.b->data.data(), p.a->size, p.b->size, choice, aff_method, use_input,
+                         ftol, it_limit, dev, -1, true, rec);
+        };
     };
     auto bad = [&](const RegState &st, const float *rec) {
         return !checkmatrix(const_cast<float *>(st.tmx), sx, sy, sz) || rec[3] < cost_bar;
     };
     // Returns the status of the library call that failed (0: all calls succeeded).  A failed call leaves tmx / b_reg / rec
     // untouched, so nothing below may use them: the caller stops the batch.
-    auto ladder = [&](RegState &st, Prepared &p, std::vector<float> &b_reg, float *rec, int choice_now, int dev, Lines &out) -> int {
+    auto ladder = [&](RegState &st, const RegCall &reg, float *rec, int choice_now, Lines &out) -> int {
         // first attempt, other scheme without the input matrix, then the input matrix itself
-        if (int status = run_reg(st, p, b_reg, rec, choice_now, st.have_itmx, dev)) return status;
+        if (int status = reg(st.tmx, rec, choice_now, st.have_itmx)) return status;
         if (bad(st, rec)) {
             out("\n\t... Attempt failed: transformation matrix problematic or cost function value %f < threshold %2.2f\n"
                 "\n\t... Change scheme and redo the registration!!!\n", rec[3], cost_bar);
-            if (int status = run_reg(st, p, b_reg, rec, choice_now == 4 ? 2 : 4, false, dev)) return status;
+            if (int status = reg(st.tmx, rec, choice_now == 4 ? 2 : 4, false)) return status;
             if (bad(st, rec) && st.have_itmx) {
                 out("\n\t... Attempt failed again: use input transformation matrix!!!\n");
                 std::memcpy(st.tmx, st.initial_tmx, sizeof st.tmx);
-                if (int status = run_reg(st, p, b_reg, rec, 0, true, dev)) return status;
+                if (int status = reg(st.tmx, rec, 0, true)) return status;
             }
         }
         return 0;
@@ -350,7 +373,7 @@ int main(int argc, char **argv) {
         if (!preprocess(p, device)) return 1;
         std::vector<float> b_reg(total);
         float rec[11] = {0};
-        const int status = ladder(base, p, b_reg, rec, reg_choice, device, out);
+        const int status = ladder(base, host_reg(p, b_reg, device), rec, reg_choice, out);
         log.direct("%s", out.text.c_str());
         if (status != 0) { printf("\t... registration of the test image failed (status %d), processing stopped !!!\n", status); return 1; }
         reg_mode = 0;
@@ -373,7 +396,52 @@ int main(int argc, char **argv) {
     std::memcpy(chain.previous, tmx0, sizeof tmx0);
     chain.have_itmx = have_itmx;
 
-    auto worker = [&](int w) {
+    // index of the first time point that failed is fail_at; a failed worker must not leave the others waiting for the chain
+    auto stop = [&](int index) {
+        int seen = fail_at.load();
+        while (index < seen && !fail_at.compare_exchange_weak(seen, index)) {}
+        { std::lock_guard<std::mutex> lock(chain.mu); }  // a waiter is either before its predicate test or asleep
+        chain.cv.notify_all();
+    };
+    // The registration of time point i according to the mode (:714-843), through `reg` (host or device pointers).
+    // 0: registered; > 0: a library call failed with that status; -1: abandoned, an earlier time point failed.
+    auto register_step = [&](size_t i, RegState &st, const RegCall &reg, float *rec, Lines &out) -> int {
+        int reg_status = 0;
+        switch (reg_mode) {
+        case 0: reg_status = reg(st.tmx, rec, 0, st.have_itmx); break;
+        case 2: {
+            std::unique_lock<std::mutex> lock(chain.mu);
+            chain.cv.wait(lock, [&] { return fail_at.load() < (int)i || chain.next >= (int)i; });
+            if (fail_at.load() < (int)i || chain.next != (int)i) return -1;  // an earlier time point failed: the chain ends there
+            lock.unlock();  // the state is this worker's alone until it advances `next`
+            if (i == 0) {
+                reg_status = ladder(st, reg, rec, reg_choice, out);
+                if (reg_status == 0) std::memcpy(chain.weighted, st.tmx, sizeof st.tmx);
+            } else {  // start from the running average, fall back to the previous matrix (:786-808)
+                std::memcpy(st.tmx, chain.weighted, sizeof st.tmx);
+                reg_status = reg(st.tmx, rec, 2, true);
+                if (reg_status == 0 && bad(st, rec)) {
+                    out("\n\t... Attempt failed: use previous transformation matrix!!!\n");
+                    std::memcpy(st.tmx, chain.previous, sizeof st.tmx);
+                    reg_status = reg(st.tmx, rec, 0, true);
+                }
+                if (reg_status == 0)
+                    for (int j = 0; j < 12; ++j) chain.weighted[j] = (float)(0.8 * chain.weighted[j] + 0.2 * st.tmx[j]);  // double arithmetic, :805-807
+            }
+            if (reg_status != 0) break;  // the chain does NOT advance from a failed registration: stop() wakes the others
+            std::memcpy(chain.previous, st.tmx, sizeof st.tmx);
+            lock.lock();
+            chain.next = (int)i + 1;
+            lock.unlock();
+            chain.cv.notify_all();
+            break;
+        }
+        case 3: reg_status = ladder(st, reg, rec, reg_choice, out); break;
+        }
+        return reg_status;
+    };
+
+    auto host_worker = [&](int w) {
         const int dev = devices[(size_t)w];
         const int n_workers = (int)devices.size();
         std::vector<float> b_reg(total), decon(total), decon_out(total), mp((size_t)(sx * sy + sy * sz + sz * sx));
@@ -381,12 +449,6 @@ int main(int argc, char **argv) {
         std::future<Pair> ahead;
         size_t ahead_i = 0;
         std::future<void> behind;
-        auto stop = [&](int index) {  // a failed worker must not leave the others waiting for the chain or the log
-            int seen = fail_at.load();
-            while (index < seen && !fail_at.compare_exchange_weak(seen, index)) {}
-            { std::lock_guard<std::mutex> lock(chain.mu); }  // a waiter is either before its predicate test or asleep
-            chain.cv.notify_all();
-        };
         for (size_t i = (size_t)w; i < points.size() && (int)i < fail_at.load(); i += (size_t)n_workers) {
             const int n = points[i];
             Lines out;
@@ -428,38 +490,8 @@ int main(int argc, char **argv) {
 
             // ---- registration (:714-843)
             RegState st = base;
-            int reg_status = 0;
-            switch (reg_mode) {
-            case 0: reg_status = run_reg(st, p, b_reg, reg_records, 0, st.have_itmx, dev); break;
-            case 2: {
-                std::unique_lock<std::mutex> lock(chain.mu);
-                chain.cv.wait(lock, [&] { return fail_at.load() < (int)i || chain.next >= (int)i; });
-                if (fail_at.load() < (int)i || chain.next != (int)i) break;  // an earlier time point failed: the chain ends there
-                lock.unlock();  // the state is this worker's alone until it advances `next`
-                if (i == 0) {
-                    reg_status = ladder(st, p, b_reg, reg_records, reg_choice, dev, out);
-                    if (reg_status == 0) std::memcpy(chain.weighted, st.tmx, sizeof st.tmx);
-                } else {  // start from the running average, fall back to the previous matrix (:786-808)
-                    std::memcpy(st.tmx, chain.weighted, sizeof st.tmx);
-                    reg_status = run_reg(st, p, b_reg, reg_records, 2, true, dev);
-                    if (reg_status == 0 && bad(st, reg_records)) {
-                        out("\n\t... Attempt failed: use previous transformation matrix!!!\n");
-                        std::memcpy(st.tmx, chain.previous, sizeof st.tmx);
-                        reg_status = run_reg(st, p, b_reg, reg_records, 0, true, dev);
-                    }
-                    if (reg_status == 0)
-                        for (int j = 0; j < 12; ++j) chain.weighted[j] = (float)(0.8 * chain.weighted[j] + 0.2 * st.tmx[j]);  // double arithmetic, :805-807
-                }
-                if (reg_status != 0) break;  // the chain does NOT advance from a failed registration: stop() below wakes the others
-                std::memcpy(chain.previous, st.tmx, sizeof st.tmx);
-                lock.lock();
-                chain.next = (int)i + 1;
-                lock.unlock();
-                chain.cv.notify_all();
-                break;
-            }
-            case 3: reg_status = ladder(st, p, b_reg, reg_records, reg_choice, dev, out); break;
-            }
+            const int reg_status = register_step(i, st, host_reg(p, b_reg, dev), reg_records, out);
+            if (reg_status < 0) break;
             if (reg_status != 0) {  // a library call failed (its message is on stderr): never write results made from stale buffers
                 out("\t... registration failed (status %d), processing stopped !!!\n", reg_status);
                 log.publish((int)i, std::move(out.text));
@@ -525,6 +557,246 @@ int main(int argc, char **argv) {
         }
         if (ahead.valid()) ahead.wait();
         if (behind.valid()) behind.get();
+    };
+
+    // ---- the same time point with everything in HBM between the readers and the writers --------------------------------
+    struct DevBuf {  // device memory from the library's pool
+        void *p = nullptr;
+        size_t bytes = 0;
+        ~DevBuf() { if (p) mil_dev_free(p); }
+        bool need(size_t b) {
+            if (b <= bytes) return true;
+            if (p) mil_dev_free(p);
+            p = nullptr;
+            bytes = 0;
+            if (mil_dev_alloc(&p, b) != 0) return false;
+            bytes = b;
+            return true;
+        }
+        float *f() const { return (float *)p; }
+    };
+    struct PinBuf {  // pinned host memory: what the TIFF codec reads into and writes from
+        void *p = nullptr;
+        size_t bytes = 0;
+        ~PinBuf() { if (p) mil_host_free(p); }
+        bool need(size_t b) {
+            if (b <= bytes) return true;
+            if (p) mil_host_free(p);
+            p = nullptr;
+            bytes = 0;
+            if (mil_host_alloc(&p, b) != 0) return false;
+            bytes = b;
+            return true;
+        }
+    };
+    struct RawStack {  // one stack as the file holds it: 16-bit samples stay 16 bits until they are on the device
+        PinBuf host;
+        unsigned int size[3] = {0, 0, 0};
+        unsigned int bits = 0;
+        size_t count() const { return (size_t)size[0] * size[1] * size[2]; }
+    };
+    auto read_raw = [&](const std::string &path, RawStack &r) {
+        r.bits = gettifinfo(const_cast<char *>(path.c_str()), r.size);  // exits on a missing file, like the reference
+        if (!r.host.need(r.count() * (r.bits == 16 ? 2 : 4))) { fprintf(stderr, "spimFusionBatch: no pinned memory for %s\n", path.c_str()); exit(1); }
+        if (r.bits == 16) readtifstack_16to16((unsigned short *)r.host.p, const_cast<char *>(path.c_str()), r.size);
+        else readtifstack((float *)r.host.p, const_cast<char *>(path.c_str()), r.size);
+    };
+
+    auto device_worker = [&](int w) {
+        const int dev = devices[(size_t)w];
+        const int n_workers = (int)devices.size();
+        if (mil_set_device(dev) != 0) { stop(w); return; }
+        void *stream = nullptr;
+        if (mil_stream_create(&stream) != 0) { stop(w); return; }
+        RawStack raw[2][2];  // [slot][view]: the slot of time point k is k's turn modulo 2 -- one is read while the other is used
+        DevBuf d_raw_a, d_raw_b, d_in_a, d_in_b, d_a_res, d_b_rot, d_b_res, d_b_reg, d_decon, d_out16, d_mp, d_mip;
+        PinBuf h_out;
+        std::vector<float> mp((size_t)(sx * sy + sy * sz + sz * sx)), scratch;
+        float reg_records[11] = {0}, decon_records[10] = {0};
+        std::future<void> ahead;
+        size_t ahead_i = 0;
+        int turn = 0;
+        std::future<void> behind;
+        bool fatal = false;
+        auto ok = [&](int status, const char *what, size_t i, Lines &out) {  // a library call on the device path
+            if (status == 0) return true;
+            out("\t... %s failed (status %d), processing stopped !!!\n", what, status);
+            log.publish((int)i, std::move(out.text));
+            stop((int)i);
+            fatal = true;
+            return false;
+        };
+        for (size_t i = (size_t)w; i < points.size() && (int)i < fail_at.load() && !fatal; i += (size_t)n_workers, turn ^= 1) {
+            const int n = points[i];
+            Lines out;
+            out("\n*** Image time point number: %d \n", n);
+            const auto t0 = std::chrono::steady_clock::now();
+            RawStack &ra = raw[turn][0], &rb = raw[turn][1];
+            if (ahead.valid() && ahead_i == i) {
+                ahead.get();
+            } else {
+                const std::string fa = name_of(dir1, base1, n), fb = name_of(dir2, base2, n);
+                const bool have_a = fexists(const_cast<char *>(fa.c_str())), have_b = fexists(const_cast<char *>(fb.c_str()));
+                if (!have_a || !have_b) {  // ends the batch HERE, in order (see the host-pointer worker)
+                    out("\t... input stack %s does not exist, processing stopped !!!\n", (have_a ? fb : fa).c_str());
+                    fprintf(stderr, "spimFusionBatch: %s does not exist\n", (have_a ? fb : fa).c_str());
+                    log.publish((int)i, std::move(out.text));
+                    stop((int)i);
+                    break;
+                }
+                read_raw(fa, ra);
+                read_raw(fb, rb);
+            }
+            {   // this worker's next time point, into the other slot, while this one is on the GPU
+                const size_t ni = i + (size_t)n_workers;
+                if (ni < points.size() && fexists(const_cast<char *>(name_of(dir1, base1, points[ni]).c_str())) &&
+                    fexists(const_cast<char *>(name_of(dir2, base2, points[ni]).c_str()))) {
+                    ahead_i = ni;
+                    RawStack *na = &raw[turn ^ 1][0], *nb = &raw[turn ^ 1][1];
+                    const std::string fa = name_of(dir1, base1, points[ni]), fb = name_of(dir2, base2, points[ni]);
+                    ahead = std::async(std::launch::async, [&read_raw, na, nb, fa, fb] { read_raw(fa, *na); read_raw(fb, *nb); });
+                }
+            }
+            if (ra.size[0] != in1[0] || ra.size[1] != in1[1] || ra.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); stop((int)i); break; }
+            if (rb.size[0] != in2[0] || rb.size[1] != in2[1] || rb.size[2] != in2[2]) { printf("\t Input image 2 size does not match !!!\n"); stop((int)i); break; }
+
+            // ---- upload (16-bit files as 16 bits) and widen on the device: (float)v like readtifstack (src/apifunc.cpp:166-183)
+            auto to_device = [&](RawStack &r, DevBuf &d_raw, DevBuf &d_in) -> float * {
+                const size_t cnt = r.count();
+                if (r.bits == 16) {
+                    if (!d_raw.need(cnt * 2) || !d_in.need(cnt * 4)) return nullptr;
+                    if (mil_upload(d_raw.p, r.host.p, cnt * 2, stream) != 0) return nullptr;
+                    if (mil_u16_to_f32(d_in.f(), (const unsigned short *)d_raw.p, cnt, stream) != 0) return nullptr;
+                    return d_in.f();
+                }
+                if (!d_in.need(cnt * 4)) return nullptr;
+                if (r.bits == 32 && mil_upload(d_in.p, r.host.p, cnt * 4, stream) != 0) return nullptr;
+                return d_in.f();  // other depths: the reader left the buffer alone, like the reference's
+            };
+            float *d_a = to_device(ra, d_raw_a, d_in_a), *d_b = to_device(rb, d_raw_b, d_in_b);
+            if (!ok(d_a && d_b ? 0 : -1, "upload of the input stacks", i, out)) break;
+            // ---- preprocessing (:666-711) on device pointers
+            if (in1[0] != size[0] || in1[1] != size[1] || in1[2] != size[2]) {
+                if (!ok(d_a_res.need(total * 4) ? mil_imresize3d(d_a_res.f(), d_a, sx, sy, sz, in1[0], in1[1], in1[2], stream) : -1, "imresize3d", i, out)) break;
+                d_a = d_a_res.f();
+            }
+            unsigned int rot_size[3] = {in2[0], in2[1], in2[2]};
+            if (op_choice != 0) {
+                if (!ok(d_b_rot.need(rb.count() * 4) ? mil_rot_y90(d_b_rot.f(), d_b, (int)in2[0], (int)in2[1], (int)in2[2], op_choice == 1 ? 1 : -1, stream) : -1,
+                        "imoperation3D", i, out)) break;
+                d_b = d_b_rot.f();
+                rot_size[0] = in2[2];
+                rot_size[2] = in2[0];
+            }
+            if (rot_size[0] != size2[0] || rot_size[1] != size2[1] || rot_size[2] != size2[2]) {
+                if (!ok(d_b_res.need((size_t)size2[0] * size2[1] * size2[2] * 4)
+                            ? mil_imresize3d(d_b_res.f(), d_b, size2[0], size2[1], size2[2], rot_size[0], rot_size[1], rot_size[2], stream) : -1,
+                        "imresize3d", i, out)) break;
+                d_b = d_b_res.f();
+            }
+            if (!ok(d_b_reg.need(total * 4) && d_decon.need(total * 4) ? mil_stream_sync(stream) : -1, "preprocessing", i, out)) break;
+            const auto t1 = std::chrono::steady_clock::now();
+
+            // ---- registration (:714-843)
+            RegState st = base;
+            const float *reg_a = d_a, *reg_b = d_b;
+            const RegCall dev_reg = [&, reg_a, reg_b](float *tmx, float *rec, int choice, bool use_input) {
+                return mil_reg3d(d_b_reg.f(), tmx, reg_a, reg_b, size, size2, choice, aff_method, use_input ? 1 : 0, ftol, it_limit, 1, rec, stream);
+            };
+            const int reg_status = register_step(i, st, dev_reg, reg_records, out);
+            if (reg_status < 0) break;
+            if (!ok(reg_status, "registration", i, out)) break;
+            if (fail_at.load() < (int)i) break;  // an earlier time point failed while this one registered: write nothing
+            out("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
+                reg_records[1], reg_records[3], reg_records[7]);
+            const std::string ns = std::to_string(n);
+            write_tmx(tmx_dir + "Matrix_" + ns + ".tmx", st.tmx);  // always saved (:859-868)
+            auto save_volume = [&](const std::string &path, const float *d_vol) {
+                scratch.resize(total);
+                if (mil_download(scratch.data(), d_vol, total * 4, stream) != 0 || mil_stream_sync(stream) != 0) return false;
+                writetifstack(const_cast<char *>(path.c_str()), scratch.data(), size, (unsigned short)in_bits);
+                return true;
+            };
+            if (save_reg1 && !ok(save_volume(reg1_dir + base1 + "reg_" + ns + ".tif", d_a) ? 0 : -1, "download", i, out)) break;
+            if (save_reg2 && !ok(save_volume(reg2_dir + base2 + "reg_" + ns + ".tif", d_b_reg.f()) ? 0 : -1, "download", i, out)) break;
+            const auto t2 = std::chrono::steady_clock::now();
+
+            // ---- joint deconvolution (:874-911)
+            if (!ok(mil_decon_dualview(d_decon.f(), d_a, d_b_reg.f(), size, psf1.data.data(), psf2.data.data(), psf1.size, 0, iters, 1,
+                                       decon_records, unmatch ? 1 : 0, bp1.data.data(), bp2.data.data(), stream),
+                    "deconvolution", i, out)) break;
+            if (fail_at.load() < (int)i) break;  // an earlier time point failed meanwhile: nothing of this one is written
+            out("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
+                decon_records[5]);
+            if (behind.valid()) behind.get();  // the previous stack has left h_out
+            {
+                const std::string path = decon_dir + "Decon_" + ns + ".tif";
+                const bool as16 = out_bits == 16;
+                int status = h_out.need(total * (as16 ? 2 : 4)) ? 0 : -1;
+                if (status == 0 && as16)  // (unsigned short)f on the device, as writetifstack does on the host (:255)
+                    status = d_out16.need(total * 2) ? mil_f32_to_u16((unsigned short *)d_out16.p, d_decon.f(), total, stream) : -1;
+                if (status == 0) status = mil_download(h_out.p, as16 ? d_out16.p : d_decon.p, total * (as16 ? 2 : 4), stream);
+                if (status == 0) status = mil_stream_sync(stream);
+                if (!ok(status, "download of the deconvolved stack", i, out)) break;
+                void *data = h_out.p;
+                unsigned int wsize[3] = {size[0], size[1], size[2]};
+                const unsigned short bits = out_bits;
+                behind = std::async(std::launch::async, [path, data, wsize, bits, as16]() mutable {
+                    if (as16) writetifstack_16to16(const_cast<char *>(path.c_str()), (unsigned short *)data, wsize);
+                    else writetifstack(const_cast<char *>(path.c_str()), (float *)data, wsize, bits);
+                });
+            }
+            const auto t3 = std::chrono::steady_clock::now();
+
+            // ---- projections (:913-943) of the stack in HBM
+            if (save_zproj || save_xproj || save_yproj) {  // mp2dgpu (src/apifunc.cpp:485-505; the Y projection hangs on the Z flag there)
+                const size_t n_mp = mp.size();
+                int status = d_mp.need(n_mp * 4) ? 0 : -1;
+                std::fill(mp.begin(), mp.end(), 0.0f);
+                if (status == 0) status = mil_upload(d_mp.p, mp.data(), n_mp * 4, stream);
+                if (status == 0 && save_zproj) status = mil_max_projection(d_mp.f(), d_decon.f(), (int)sx, (int)sy, (int)sz, 1, stream);
+                if (status == 0 && save_xproj) status = mil_max_projection(d_mp.f() + sx * sy, d_decon.f(), (int)sx, (int)sy, (int)sz, 3, stream);
+                if (status == 0 && save_zproj) status = mil_max_projection(d_mp.f() + sx * sy + sy * sz, d_decon.f(), (int)sx, (int)sy, (int)sz, 2, stream);
+                if (status == 0) status = mil_download(mp.data(), d_mp.p, n_mp * 4, stream);
+                if (status == 0) status = mil_stream_sync(stream);
+                if (!ok(status, "max projections", i, out)) break;
+                unsigned int s2[3] = {0, 0, 1};
+                if (save_zproj) { s2[0] = (unsigned)sx; s2[1] = (unsigned)sy; writetifstack(const_cast<char *>((mp_xy + "MP_XY_" + ns + ".tif").c_str()), mp.data(), s2, out_bits); }
+                if (save_xproj) { s2[0] = (unsigned)sy; s2[1] = (unsigned)sz; writetifstack(const_cast<char *>((mp_yz + "MP_YZ_" + ns + ".tif").c_str()), mp.data() + sx * sy, s2, out_bits); }
+                if (save_yproj) { s2[0] = (unsigned)sz; s2[1] = (unsigned)sx; writetifstack(const_cast<char *>((mp_zx + "MP_ZX_" + ns + ".tif").c_str()), mp.data() + sx * sy + sy * sz, s2, out_bits); }
+            }
+            for (int axis = 1; axis <= 2 && !fatal; ++axis) {
+                if (!(axis == 1 ? save_3dx : save_3dy)) continue;
+                const long long project_num = 36;
+                int s3i[3] = {0, 0, 0};
+                int status = mil_mip3d(nullptr, d_decon.f(), (int)sx, (int)sy, (int)sz, axis, project_num, s3i, stream);
+                const size_t cnt = (size_t)s3i[0] * s3i[1] * s3i[2];
+                if (status == 0) status = d_mip.need(cnt * 4) ? mil_mip3d(d_mip.f(), d_decon.f(), (int)sx, (int)sy, (int)sz, axis, project_num, s3i, stream) : -1;
+                scratch.resize(cnt);
+                if (status == 0) status = mil_download(scratch.data(), d_mip.p, cnt * 4, stream);
+                if (status == 0) status = mil_stream_sync(stream);
+                if (!ok(status, "3-D max projections", i, out)) break;
+                unsigned int s3[3] = {(unsigned)s3i[0], (unsigned)s3i[1], (unsigned)s3i[2]};
+                writetifstack(const_cast<char *>(((axis == 1 ? mp_3dx + "MP_3D_Xaxis_" : mp_3dy + "MP_3D_Yaxis_") + ns + ".tif").c_str()),
+                              scratch.data(), s3, out_bits);
+            }
+            if (fatal) break;
+            const auto t4 = std::chrono::steady_clock::now();
+            out("\tTime cost: preprocessing %2.3f s, registration %2.3f s, deconvolution %2.3f s, projections %2.3f s\n", sec(t0, t1),
+                sec(t1, t2), sec(t2, t3), sec(t3, t4));
+            log.publish((int)i, std::move(out.text));
+        }
+        if (ahead.valid()) ahead.wait();
+        if (behind.valid()) behind.get();
+        (void)mil_stream_sync(stream);
+        mil_stream_destroy(stream);
+    };
+
+    const char *path_env = getenv("MIL_BATCH_PATH");
+    const bool host_path = path_env && !strcmp(path_env, "host");
+    auto worker = [&](int w) {
+        if (host_path) host_worker(w);
+        else device_worker(w);
     };
 
     if (devices.size() == 1) {

@@ -454,6 +454,106 @@ extern "C" int decon_dualview(float *h_decon, float *h_img1, float *h_img2, unsi
     });
 }
 
+// ---- the same calls on device-resident volumes (include/mil_device.h) -------------------------------------------------------
+// A host that keeps its stacks in HBM (the time-lapse batch tool) runs the stages of decon_singleview / decon_dualview without
+// the two PCIe trips: same engine and OTF cache, same pad / initial estimate / RL loop / crop, hence the same bits.  The
+// images are device pointers of imSize floats (read only: the engine works on its own padded copies), the PSFs stay host
+// pointers (small, and the OTF cache finds them by content); d_decon receives imSize floats.  GPU mode only; records as in
+// the host-pointer calls.  Runs on the cached engine's own stream, which first waits for `stream` (the producer of the
+// images); the call returns when d_decon is complete.
+namespace {
+
+void device_in(float *d_dst, const float *d_src, const Geometry &g, hipStream_t s) {
+    if (g.padded) k::pad_stack(d_dst, d_src, g.box, g.im, s);  // reference src/api_decon.cpp:225-231
+    else MIL_HIP(hipMemcpyAsync(d_dst, d_src, g.n_im * sizeof(float), hipMemcpyDeviceToDevice, s));
+}
+
+void device_out(float *d_dst, const float *d_src, const Geometry &g, hipStream_t s) {
+    if (g.padded) k::crop_stack(d_dst, d_src, g.im, g.box, s);  // :237-243
+    else MIL_HIP(hipMemcpyAsync(d_dst, d_src, g.n_im * sizeof(float), hipMemcpyDeviceToDevice, s));
+    MIL_HIP(hipStreamSynchronize(s));
+}
+
+void wait_for_producer(hipStream_t engine_stream, hipStream_t producer) {
+    if (producer == engine_stream) return;
+    hipEvent_t ev;
+    MIL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const hipError_t e1 = hipEventRecord(ev, producer);
+    const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(engine_stream, ev, 0) : e1;
+    (void)hipEventDestroy(ev);
+    MIL_HIP(e2);
+}
+
+int decon_device(float *d_decon, const float *d_img1, const float *d_img2, const unsigned int *imSize, const float *h_psf1,
+                 const float *h_psf2, const unsigned int *psfSize, bool dual, bool flagConstInitial, int iters, bool verbose,
+                 float *deconRecords, bool flagUnmatch, const float *h_psf_bp1, const float *h_psf_bp2, hipStream_t producer) {
+    const double t_start = now_s();
+    const Geometry g = make_geometry(imSize, psfSize);
+    int device = 0;
+    MIL_HIP(hipGetDevice(&device));
+    deconRecords[1] = free_mb();
+    deconRecords[0] = 1.f;
+    const double t_init = now_s();
+    CacheLease lease(device, g.box);
+    DeconCache::Entry &cache = *lease.e;
+    DeconEngine &eng = lease.engine();
+    hipStream_t s = eng.stream();
+    DeviceBuffer<float> dA(g.n_box), dB(dual ? g.n_box : 0), dE(g.n_box), dPsf(g.n_psf);
+    deconRecords[2] = free_mb();
+    const float2 *dOtf1, *dOtfBp1, *dOtf2 = nullptr, *dOtfBp2 = nullptr;
+    view_otfs(cache, eng, dOtf1, dOtfBp1, dPsf, h_psf1, h_psf_bp1, flagUnmatch, g);
+    if (dual) view_otfs(cache, eng, dOtf2, dOtfBp2, dPsf, h_psf2, h_psf_bp2, flagUnmatch, g);
+    wait_for_producer(s, producer);
+    device_in(dA, d_img1, g, s);
+    if (dual) {
+        device_in(dB, d_img2, g, s);
+        eng.init_dual(dA, dB, dE, flagConstInitial);
+    } else {
+        eng.init_single(dA, dE, flagConstInitial);
+    }
+    MIL_HIP(hipStreamSynchronize(s));
+    const double t_loop = now_s();
+    if (dual) eng.run_dual(dE, dA, dB, dOtf1, dOtf2, dOtfBp1, dOtfBp2, iters);
+    else eng.run_single(dE, dA, dOtf1, dOtfBp1, iters);
+    eng.synchronize();
+    const double t_done = now_s();
+    if (verbose && !dual) printf("...Time cost for decon is %2.3f s\n", t_done - t_loop);
+    deconRecords[3] = free_mb();
+    device_out(d_decon, dE, g, s);
+    deconRecords[4] = free_mb();
+    const double t_end = now_s();
+    deconRecords[5] = deconRecords[4];
+    deconRecords[6] = (float)(t_init - t_start);
+    deconRecords[7] = (float)(t_loop - t_init);
+    deconRecords[8] = (float)(t_done - t_loop);
+    deconRecords[9] = (float)(t_end - t_start);
+    if (verbose && dual) printf("\t... deconvolution done !!! \n");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mil_decon_singleview(float *d_decon, const float *d_img, const unsigned int *imSize, const float *h_psf,
+                                    const unsigned int *psfSize, int flagConstInitial, int itNumForDecon, int verbose,
+                                    float *deconRecords, int flagUnmatch, const float *h_psf_bp, void *stream) {
+    return guarded("mil_decon_singleview", [&]() -> int {
+        TraceRange trace("mil_decon_singleview");
+        return decon_device(d_decon, d_img, nullptr, imSize, h_psf, nullptr, psfSize, false, flagConstInitial != 0, itNumForDecon,
+                            verbose != 0, deconRecords, flagUnmatch != 0, h_psf_bp, nullptr, (hipStream_t)stream);
+    });
+}
+
+extern "C" int mil_decon_dualview(float *d_decon, const float *d_img1, const float *d_img2, const unsigned int *imSize,
+                                  const float *h_psf1, const float *h_psf2, const unsigned int *psfSize, int flagConstInitial,
+                                  int itNumForDecon, int verbose, float *deconRecords, int flagUnmatch, const float *h_psf_bp1,
+                                  const float *h_psf_bp2, void *stream) {
+    return guarded("mil_decon_dualview", [&]() -> int {
+        TraceRange trace("mil_decon_dualview");
+        return decon_device(d_decon, d_img1, d_img2, imSize, h_psf1, h_psf2, psfSize, true, flagConstInitial != 0, itNumForDecon,
+                            verbose != 0, deconRecords, flagUnmatch != 0, h_psf_bp1, h_psf_bp2, (hipStream_t)stream);
+    });
+}
+
 // Dead upstream (its guard at src/api_decon.cpp:1133 is always true, so it always returns 1
 // before doing any work); kept so the symbol resolves.
 extern "C" int fusion_dualview(float *, float *, float *, float *, float *, float *, float *, unsigned int *,

@@ -50,9 +50,43 @@ extern "C" int atrans3dgpu(float *h_reg, float *iTmx, float *h_img2, unsigned in
     });
 }
 
-extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1,
-                     unsigned int *imSize2, int regChoice, int affMethod, bool flagTmx, float FTOL, int itLimit,
-                     int deviceNum, int gpuMemMode, bool verbose, float *records) {
+namespace {
+
+// reg3d (reference src/api_reg.cpp:264-607) between its transfers: target and source (already aligned to the target's box)
+// in device memory, the registered source left in d_reg.  Shared by the host-pointer entry reg3d and the device-pointer
+// entry mil_reg3d.  records[8..10] and [7] are the caller's.
+void reg3d_core(float *d_reg, float *iTmx, const float *d_t, const float *d_s, Dims d1, int regChoice, int affMethod, bool flagTmx,
+                float FTOL, int itLimit, bool verbose, float *records, hipStream_t s) {
+    const int method = (regChoice == 0) ? 0 : affMethod;  // :412
+    if (regChoice == 1 || regChoice == 3) {  // phasor: pixel-level translation (:418-446)
+        long long sh[3];
+        phasor_shift(sh, d_t, d_s, d1, s);
+        for (int j = 0; j < 12; ++j) iTmx[j] = 0.f;
+        iTmx[0] = iTmx[5] = iTmx[10] = 1.f;
+        iTmx[3] = (float)sh[0]; iTmx[7] = (float)sh[1]; iTmx[11] = (float)sh[2];
+        if (regChoice == 1) {  // the shifted source IS the result
+            k::shift_volume(d_reg, d_s, d1, -sh[0], -sh[1], -sh[2], false, s);
+            return;
+        }
+        flagTmx = true;  // regChoice 3: affine from that translation
+    }
+    if (regChoice == 4) {  // 2-D MIP shifts first, then affine from that translation (:448-497)
+        if (verbose) printf("\t... 2D MIP registration ... \n");
+        float shift[3];
+        mip_shift_search(shift, d_t, d_s, d1, s);
+        for (int j = 0; j < 12; ++j) iTmx[j] = 0.f;
+        iTmx[0] = iTmx[5] = iTmx[10] = 1.f;
+        iTmx[3] = shift[0]; iTmx[7] = shift[1]; iTmx[11] = shift[2];
+        if (verbose) {
+            printf("\t... shift translation, X: %2.1f; Y: %2.1f; Z: %2.1f\n", shift[0], shift[1], shift[2]);
+            printf("\t... 2D MIP registration completed. \n\t... 3D registration ... \n");
+        }
+        flagTmx = true;
+    }
+    reg3d_affine_device(d_reg, iTmx, d_t, d_s, d1, method, flagTmx, FTOL, itLimit, verbose, records, s);
+}
+
+int reg3d_check_args(int regChoice, int gpuMemMode) {
     if (gpuMemMode == 0) {  // same answer as the reference, src/api_reg.cpp:390-393
         printf("\n ****CPU registraion function is under developing **** \n");
         return -1;
@@ -65,7 +99,15 @@ extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, un
         printf("\n*** Wrong registration choice is setup, no registraiton performed !!! **** \n");
         return 1;  // :512-514
     }
+    return 0;
+}
 
+}  // namespace
+
+extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, unsigned int *imSize1,
+                     unsigned int *imSize2, int regChoice, int affMethod, bool flagTmx, float FTOL, int itLimit,
+                     int deviceNum, int gpuMemMode, bool verbose, float *records) {
+    if (const int bad = reg3d_check_args(regChoice, gpuMemMode)) return bad;
     return guarded("reg3d", [&]() -> int {
         TraceRange trace("libapi::reg3d");
         const auto t0 = std::chrono::steady_clock::now();
@@ -89,43 +131,46 @@ extern "C" int reg3d(float *h_reg, float *iTmx, float *h_img1, float *h_img2, un
         }
         MIL_HIP(hipMemcpyAsync(d_t.get(), h_img1, n1 * sizeof(float), hipMemcpyHostToDevice, sg.s));
         records[9] = free_mb();
-        const int method = (regChoice == 0) ? 0 : affMethod;  // :412
-        if (regChoice == 1 || regChoice == 3) {  // phasor: pixel-level translation (:418-446)
-            long long sh[3];
-            phasor_shift(sh, d_t.get(), d_s.get(), d1, sg.s);
-            for (int j = 0; j < 12; ++j) iTmx[j] = 0.f;
-            iTmx[0] = iTmx[5] = iTmx[10] = 1.f;
-            iTmx[3] = (float)sh[0]; iTmx[7] = (float)sh[1]; iTmx[11] = (float)sh[2];
-            if (regChoice == 1) {  // the shifted source IS the result
-                k::shift_volume(d_reg.get(), d_s.get(), d1, -sh[0], -sh[1], -sh[2], false, sg.s);
-                MIL_HIP(hipMemcpyAsync(h_reg, d_reg.get(), n1 * sizeof(float), hipMemcpyDeviceToHost, sg.s));
-                MIL_HIP(hipStreamSynchronize(sg.s));
-                records[10] = free_mb();
-                records[7] = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                return 0;
-            }
-            flagTmx = true;  // regChoice 3: affine from that translation
-        }
-        if (regChoice == 4) {  // 2-D MIP shifts first, then affine from that translation (:448-497)
-            if (verbose) printf("\t... 2D MIP registration ... \n");
-            float shift[3];
-            mip_shift_search(shift, d_t.get(), d_s.get(), d1, sg.s);
-            for (int j = 0; j < 12; ++j) iTmx[j] = 0.f;
-            iTmx[0] = iTmx[5] = iTmx[10] = 1.f;
-            iTmx[3] = shift[0]; iTmx[7] = shift[1]; iTmx[11] = shift[2];
-            if (verbose) {
-                printf("\t... shift translation, X: %2.1f; Y: %2.1f; Z: %2.1f\n", shift[0], shift[1], shift[2]);
-                printf("\t... 2D MIP registration completed. \n\t... 3D registration ... \n");
-            }
-            flagTmx = true;
-        }
-        reg3d_affine_device(d_reg.get(), iTmx, d_t.get(), d_s.get(), d1, method, flagTmx, FTOL, itLimit, verbose,
-                            records, sg.s);
+        reg3d_core(d_reg.get(), iTmx, d_t.get(), d_s.get(), d1, regChoice, affMethod, flagTmx, FTOL, itLimit, verbose, records, sg.s);
         MIL_HIP(hipMemcpyAsync(h_reg, d_reg.get(), n1 * sizeof(float), hipMemcpyDeviceToHost, sg.s));
         MIL_HIP(hipStreamSynchronize(sg.s));
         records[10] = free_mb();
         records[7] = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (verbose) printf("\t... registration done !!! \n");
+        if (verbose && regChoice != 1) printf("\t... registration done !!! \n");
+        return 0;
+    });
+}
+
+// reg3d on device-resident volumes (include/mil_device.h): the same stages, the same arithmetic, no transfers.  d_reg,
+// d_img1 and d_img2 must not overlap; the volumes are only read.  The call returns when d_reg is complete (the registration
+// synchronises `stream` with every cost evaluation anyway).
+extern "C" int mil_reg3d(float *d_reg, float *iTmx, const float *d_img1, const float *d_img2, const unsigned int *imSize1,
+                         const unsigned int *imSize2, int regChoice, int affMethod, int flagTmx, float FTOL, int itLimit,
+                         int verbose, float *records, void *stream) {
+    if (const int bad = reg3d_check_args(regChoice, 1)) return bad;
+    return guarded("mil_reg3d", [&]() -> int {
+        TraceRange trace("mil_reg3d");
+        const auto t0 = std::chrono::steady_clock::now();
+        hipStream_t s = (hipStream_t)stream;
+        records[8] = free_mb();
+        if (verbose) printf("\t... GPU free memory before registration is %.0f MB\n", records[8]);
+        const Dims d1{(long long)imSize1[0], (long long)imSize1[1], (long long)imSize1[2]};
+        const Dims d2{(long long)imSize2[0], (long long)imSize2[1], (long long)imSize2[2]};
+        records[0] = 1.f;
+        DeviceBuffer<float> aligned;
+        const float *d_s = d_img2;
+        if (!(d1 == d2)) {  // centred crop / zero-pad of the source to the target box (:401-406)
+            aligned.alloc((size_t)d1.count());
+            k::align_size(aligned.get(), d_img2, d1, d2, s);
+            d_s = aligned.get();
+        }
+        records[9] = free_mb();
+        reg3d_core(d_reg, iTmx, d_img1, d_s, d1, regChoice, affMethod, flagTmx != 0, FTOL, itLimit, verbose != 0, records, s);
+        MIL_HIP(hipStreamSynchronize(s));
+        aligned.release();
+        records[10] = free_mb();
+        records[7] = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (verbose && regChoice != 1) printf("\t... registration done !!! \n");
         return 0;
     });
 }

@@ -162,6 +162,62 @@ int mil_resample_mip_z(float *d_plane, const float *d_src, int bx, int by, int b
     });
 }
 
+// ---- device memory, streams and transfers for hosts built without the HIP headers (cli/*.cpp compile with g++ alone) -----
+int mil_dev_alloc(void **d_ptr, size_t bytes) {
+    *d_ptr = nullptr;
+    return guarded("mil_dev_alloc", [&] { *d_ptr = pool_alloc(bytes ? bytes : 1); return 0; });
+}
+void mil_dev_free(void *d_ptr) {
+    if (d_ptr) (void)guarded("mil_dev_free", [&] { pool_free(d_ptr); return 0; });
+}
+int mil_host_alloc(void **h_ptr, size_t bytes) {
+    *h_ptr = nullptr;
+    return guarded("mil_host_alloc", [&] { MIL_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault)); return 0; });
+}
+void mil_host_free(void *h_ptr) {
+    if (h_ptr) (void)hipHostFree(h_ptr);
+}
+int mil_stream_create(void **stream) {
+    *stream = nullptr;
+    return guarded("mil_stream_create", [&] {
+        hipStream_t s = nullptr;
+        MIL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *stream = s;
+        return 0;
+    });
+}
+void mil_stream_destroy(void *stream) {
+    if (stream) (void)hipStreamDestroy(as_stream(stream));
+}
+int mil_stream_sync(void *stream) {
+    return guarded("mil_stream_sync", [&] { MIL_HIP(hipStreamSynchronize(as_stream(stream))); return 0; });
+}
+int mil_upload(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    return guarded("mil_upload", [&] { MIL_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, as_stream(stream))); return 0; });
+}
+int mil_download(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    return guarded("mil_download", [&] { MIL_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, as_stream(stream))); return 0; });
+}
+int mil_u16_to_f32(float *d_out, const unsigned short *d_in, size_t n, void *stream) {
+    return guarded("mil_u16_to_f32", [&] { k::u16_to_f32(d_out, d_in, n, as_stream(stream)); return 0; });
+}
+int mil_f32_to_u16(unsigned short *d_out, const float *d_in, size_t n, void *stream) {
+    return guarded("mil_f32_to_u16", [&] { k::f32_to_u16(d_out, d_in, n, as_stream(stream)); return 0; });
+}
+// imresize3d (src/apifunc.cpp:429-446) on device pointers: the same diagonal matrix through the same resampler
+int mil_imresize3d(float *d_out, const float *d_in, long long sx, long long sy, long long sz, long long sx2, long long sy2,
+                   long long sz2, void *stream) {
+    return guarded("mil_imresize3d", [&] {
+        k::Affine12 m;
+        for (float &v : m.m) v = 0.0f;
+        m.m[0] = float(sx2) / float(sx);
+        m.m[5] = float(sy2) / float(sy);
+        m.m[10] = float(sz2) / float(sz);
+        k::affine_resample(d_out, d_in, Dims{sx, sy, sz}, Dims{sx2, sy2, sz2}, m, as_stream(stream));
+        return 0;
+    });
+}
+
 int mil_decon_create(mil_decon **out, int nx, int ny, int nz, void *stream) {
     return mil_decon_create_backend(out, nx, ny, nz, stream, MIL_BACKEND_AUTO);
 }

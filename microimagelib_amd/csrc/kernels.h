@@ -18,6 +18,8 @@ void init_dual(float *A, float *B, float *E, size_t n, float eps, hipStream_t s)
 void fill(float *out, float v, size_t n, hipStream_t s);
 void scale(float *out, const float *in, float c, size_t n, hipStream_t s);      // out = in * c
 void add_value(float *out, const float *in, float c, size_t n, hipStream_t s);  // out = in + c
+void u16_to_f32(float *out, const unsigned short *in, size_t n, hipStream_t s);   // (float)v: readtifstack's widening
+void f32_to_u16(unsigned short *out, const float *in, size_t n, hipStream_t s);   // (unsigned short)f: writetifstack's C cast
 
 // ---- reductions (float64 accumulation, deterministic two-stage) ------------
 enum ReduceOp { kSum = 0, kSumSqShifted = 1 };

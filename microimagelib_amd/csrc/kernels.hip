@@ -489,7 +489,33 @@ inline int cdiv2(long long a) { return (int)(a / 2); }  // C truncation toward z
 
 }  // namespace
 
+// 16-bit stacks on the device: what readtifstack / writetifstack do on the host (reference src/apifunc.cpp:166-183: every
+// sample widened to float; :255: the C cast `(unsigned short)f`, i.e. truncation toward zero, low 16 bits of the integer --
+// csrc/tiff_io.cpp writes (uint16_t)(long long)f, and so does this kernel; values beyond the long long range and NaN give
+// 0 like the x86 conversion's "integer indefinite" does).
+__global__ __launch_bounds__(kBlock) void u16_to_f32_kernel(float *__restrict__ out, const unsigned short *__restrict__ in, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = (float)in[i];
+}
+__global__ __launch_bounds__(kBlock) void f32_to_u16_kernel(unsigned short *__restrict__ out, const float *__restrict__ in, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const float v = in[i];
+        const bool fits = v > -9.2e18f && v < 9.2e18f;
+        out[i] = fits ? (unsigned short)(long long)v : (unsigned short)0;
+    }
+}
+
 // ---- launchers --------------------------------------------------------------
+void u16_to_f32(float *out, const unsigned short *in, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(u16_to_f32_kernel, dim3(flat_grid(n)), dim3(kBlock), 0, s, out, in, n);
+    MIL_HIP(hipGetLastError());
+}
+void f32_to_u16(unsigned short *out, const float *in, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(f32_to_u16_kernel, dim3(flat_grid(n)), dim3(kBlock), 0, s, out, in, n);
+    MIL_HIP(hipGetLastError());
+}
+
 void rl_ratio(float *T, const float *A, size_t n, hipStream_t s) { launch_inplace2(T, A, n, RatioOp{}, s); }
 
 void rl_update(float *E, const float *T, size_t n, float eps, hipStream_t s) {

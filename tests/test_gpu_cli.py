@@ -210,10 +210,12 @@ def test_spimFusionBatch_two_workers_on_one_device(tmp_path, reg_mode):
         out = tmp_path / f"out_{name}"
         args = _batch_args(tmp_path, out, reg_mode)
         args[-1] = devices
-        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, MIL_BATCH_WORKERS_PER_DEVICE="1"))  # "0" is ONE worker here (the default is two)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[name] = out
     assert "2 workers on GPU devices 0,0" in open(outs["two"] / "ProcessingLog.txt").read()
+    assert "workers on GPU devices" not in open(outs["one"] / "ProcessingLog.txt").read()
     for sub, names in (("Decon", [f"Decon_{t}.tif" for t in range(3)]), ("TMX", [f"Matrix_{t}.tmx" for t in range(3)]),
                        (os.path.join("Decon", "MP_ZProj"), [f"MP_XY_{t}.tif" for t in range(3)]),
                        ("RegB", [f"SPIMB_reg_{t}.tif" for t in range(3)])):
@@ -221,3 +223,48 @@ def test_spimFusionBatch_two_workers_on_one_device(tmp_path, reg_mode):
             a = open(outs["one"] / sub / n, "rb").read()
             b = open(outs["two"] / sub / n, "rb").read()
             assert a == b, (sub, n)
+
+
+def test_spimFusionBatch_device_path_all_stages_equal_reference_main(tmp_path):
+    """Our main keeps a time point in HBM from the TIFF reader to the TIFF writer (include/mil_device.h stage entries:
+    mil_imresize3d, mil_rot_y90, mil_reg3d, mil_decon_dualview, mil_max_projection, mil_mip3d, 16-bit conversions on the
+    device).  With every stage switched on -- 16-bit input stacks, view A resized along z, view B rotated about y AND resized,
+    registration, both registered views saved, deconvolution, the three 2-D and the two 36-angle 3-D projections, 16-bit
+    output -- every file it writes is, byte for byte, the file the reference's own main writes through the host-pointer
+    calls of the same library, and the file our main writes on its host-pointer path (MIL_BATCH_PATH=host)."""
+    from microimagelib_amd import api
+    ours, ref = _need("spimFusionBatch", "ours"), _need("spimFusionBatch", "reference")
+    psf_a = do.gaussian_psf((7, 7, 7), (1.5, 1.0, 1.0))
+    psf_b = do.gaussian_psf((7, 7, 7), (1.0, 1.0, 1.5))
+    os.makedirs(tmp_path / "SPIMA")
+    os.makedirs(tmp_path / "SPIMB")
+    api.writetifstack(str(tmp_path / "pa.tif"), psf_a, 32)
+    api.writetifstack(str(tmp_path / "pb.tif"), psf_b, 32)
+    for t in range(3):  # A: z sampled 2x coarser; B: acquired rotated, its x (-> z after the rotation) 2x coarser
+        a = do.synthetic_view((12, 40, 48), psf_a, seed=t, noise_seed=10 + t, n_blobs=10)
+        b = do.synthetic_view((48, 40, 12), psf_b, seed=t, noise_seed=20 + t, n_blobs=10)
+        api.writetifstack(str(tmp_path / "SPIMA" / f"SPIMA_{t}.tif"), a, 16)
+        api.writetifstack(str(tmp_path / "SPIMB" / f"SPIMB_{t}.tif"), b, 16)
+
+    def args(out):
+        return [str(out) + "/", str(tmp_path / "SPIMA") + "/", str(tmp_path / "SPIMB") + "/", "SPIMA_", "SPIMB_", "0", "2", "1", "1",
+                "1", "1", "2", "2", "1", "1", "3", "-1", "0", "none", "0.001", "120", "1", "1", str(tmp_path / "pa.tif"),
+                str(tmp_path / "pb.tif"), "3", "1", "1", "1", "1", "1", "16", "0", "0"]
+    outs = {}
+    for name, exe, env in (("device", ours, {}), ("host", ours, {"MIL_BATCH_PATH": "host"}), ("ref", ref, {})):
+        out = tmp_path / f"out_{name}"
+        r = subprocess.run([exe] + args(out), capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0, name + r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = out
+    files = []
+    for root, _, names in os.walk(outs["ref"]):
+        for n in names:
+            if n != "ProcessingLog.txt":
+                files.append(os.path.relpath(os.path.join(root, n), outs["ref"]))
+    assert len(files) == 3 * (1 + 1 + 2 + 3 + 2), sorted(files)  # per time point: Decon, matrix, RegA + RegB, XY / YZ / ZX, 3-D x / y
+    for f in sorted(files):
+        want = open(outs["ref"] / f, "rb").read()
+        assert open(outs["device"] / f, "rb").read() == want, f"device path: {f}"
+        assert open(outs["host"] / f, "rb").read() == want, f"host path: {f}"
+    d0 = api.readtifstack(str(outs["device"] / "Decon" / "Decon_0.tif"))
+    assert d0.shape == (24, 40, 48) and d0.max() > 0

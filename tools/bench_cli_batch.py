@@ -70,14 +70,17 @@ def main():
                 w + "/pa.tif", w + "/pb.tif", str(args.iters), "0", "0", "1", "0", "0", "16", "0", devices]
 
     res = {}
-    for name, exe in (("reference main, sequential I/O", os.path.join(ROOT, "oracle", "_ref", "cli", "spimFusionBatch")),
-                      ("our main, read-ahead + write-behind", os.path.join(ROOT, "microimagelib_amd", "bin", "spimFusionBatch"))):
+    ours_exe = os.path.join(ROOT, "microimagelib_amd", "bin", "spimFusionBatch")
+    for name, exe, env in (("reference main, sequential I/O", os.path.join(ROOT, "oracle", "_ref", "cli", "spimFusionBatch"), {}),
+                           ("our main, host-pointer calls (MIL_BATCH_PATH=host), read-ahead + write-behind, one worker", ours_exe, {"MIL_BATCH_PATH": "host", "MIL_BATCH_WORKERS_PER_DEVICE": "1"}),
+                           ("our main, time point resident in HBM, read-ahead + write-behind, one worker", ours_exe, {"MIL_BATCH_WORKERS_PER_DEVICE": "1"}),
+                           ("our main, time point resident in HBM, read-ahead + write-behind, two workers (the default)", ours_exe, {})):
         if not os.path.exists(exe) or (args.skip_reference and "reference" in name):
             res[name] = None
             continue
-        out = w + "/out_" + ("ref" if "reference" in name else "ours")
+        out = w + "/out_" + ("ref" if "reference" in name else ("host" if "MIL_BATCH_PATH" in env else ("one" if env else "ours")))
         t0 = time.perf_counter()
-        r = subprocess.run([exe] + cli_args(out), capture_output=True, text=True, timeout=1800)
+        r = subprocess.run([exe] + cli_args(out), capture_output=True, text=True, timeout=1800, env=dict(os.environ, **env))
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             raise SystemExit(r.stdout[-1500:] + r.stderr[-1500:])
@@ -111,8 +114,37 @@ def main():
                     print("\n".join(l for l in r.stdout.splitlines() if "rror" in l or "libapi" in l or "fail" in l)[-3000:], file=sys.stderr)
     same = None
     if all(v for k, v in res.items() if "worker" not in k) and not args.skip_reference:
-        same = all(np.array_equal(api.readtifstack(f"{w}/out_ref/Decon/Decon_{t}.tif"),
-                                  api.readtifstack(f"{w}/out_ours/Decon/Decon_{t}.tif")) for t in range(args.time_points))
+        same = all(open(f"{w}/out_ref/Decon/Decon_{t}.tif", "rb").read() == open(f"{w}/out_ours/Decon/Decon_{t}.tif", "rb").read() ==
+                   open(f"{w}/out_host/Decon/Decon_{t}.tif", "rb").read() for t in range(args.time_points))
+    # the device-resident pipeline (batch.run_sharded + FusionPipeline, what bench.py's config-5 figure runs) on THE SAME
+    # quantised stacks, read once and kept in HBM: what the tool could reach if file I/O cost nothing
+    if args.reg_mode in (0, 3):
+        from microimagelib_amd import batch
+        pairs = {t: (torch.from_numpy(api.readtifstack(f"{w}/SPIMA/SPIMA_{t}.tif")).cuda(),
+                     torch.from_numpy(api.readtifstack(f"{w}/SPIMB/SPIMB_{t}.tif")).cuda()) for t in range(args.time_points)}
+        psf_a = torch.from_numpy(bench.gaussian_psf(bench.PSF_SHAPE, sig_a)).cuda()
+        psf_b = torch.from_numpy(bench.gaussian_psf(bench.PSF_SHAPE, sig_b)).cuda()
+        pipes = [batch.FusionPipeline(bench.SHAPE, psf_a, psf_b, iters=args.iters, mips="xy") for _ in range(2)]
+        pipe = pipes[0]
+        pol = lambda: batch.RegPolicy(reg_mode=args.reg_mode, reg_choice=2, aff_method=6, ftol=1e-4, it_limit=3000)
+        common = dict(load_pair=lambda t: pairs[t], policy=None, reg_fn=pipe.reg_fn, check_fn=pipe.check_fn, mip_shape=pipe.mip_shape,
+                      device="cuda")
+        runs = {"one time point in flight (deconvolution of i overlapped with the registration of i + 1)":
+                    lambda tps: batch.run_sharded(tps, fuse_pair=pipe.fuse_pair, overlap=True, **dict(common, policy=pol())),
+                "two time points in flight (two host threads, as the tool's two workers)":
+                    lambda tps: batch.run_sharded(tps, fuse_pair=[q.fuse_pair for q in pipes], lanes=2, **dict(common, policy=pol()))}
+        for label, run in runs.items():
+            run([0, 1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(list(range(args.time_points)))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["device-resident pipeline on the same quantised stacks, no file I/O, " + label] = {
+                "seconds": round(dt, 3), "time_points_per_s": round(args.time_points / dt, 3)}
+        for q in pipes:
+            q.close()
+        del pairs
     print(json.dumps({"workload": f"spimFusionBatch CLI, {args.time_points} time points 512x512x256, 16-bit TIFF in/out, "
                                   f"regMode {args.reg_mode}, {args.iters} RL iterations, process start to exit"
                                   + (f" ({args.distinct} distinct input pairs, the rest symlinked)" if args.distinct else ""),
