@@ -404,7 +404,9 @@ int main(int argc, char **argv) {
         chain.cv.notify_all();
     };
     // The registration of time point i according to the mode (:714-843), through `reg` (host or device pointers).
-    // 0: registered; > 0: a library call failed with that status; -1: abandoned, an earlier time point failed.
+    // 0: registered; kAbandoned: an earlier time point failed, nothing was done; anything else: the status of the library
+    // call that failed (libapi.h returns 1 or -1).
+    constexpr int kAbandoned = INT_MIN;
     auto register_step = [&](size_t i, RegState &st, const RegCall &reg, float *rec, Lines &out) -> int {
         int reg_status = 0;
         switch (reg_mode) {
@@ -412,7 +414,7 @@ int main(int argc, char **argv) {
         case 2: {
             std::unique_lock<std::mutex> lock(chain.mu);
             chain.cv.wait(lock, [&] { return fail_at.load() < (int)i || chain.next >= (int)i; });
-            if (fail_at.load() < (int)i || chain.next != (int)i) return -1;  // an earlier time point failed: the chain ends there
+            if (fail_at.load() < (int)i || chain.next != (int)i) return kAbandoned;  // an earlier time point failed: the chain ends there
             lock.unlock();  // the state is this worker's alone until it advances `next`
             if (i == 0) {
                 reg_status = ladder(st, reg, rec, reg_choice, out);
@@ -491,7 +493,7 @@ int main(int argc, char **argv) {
             // ---- registration (:714-843)
             RegState st = base;
             const int reg_status = register_step(i, st, host_reg(p, b_reg, dev), reg_records, out);
-            if (reg_status < 0) break;
+            if (reg_status == kAbandoned) break;
             if (reg_status != 0) {  // a library call failed (its message is on stderr): never write results made from stale buffers
                 out("\t... registration failed (status %d), processing stopped !!!\n", reg_status);
                 log.publish((int)i, std::move(out.text));
@@ -704,7 +706,7 @@ int main(int argc, char **argv) {
                 return mil_reg3d(d_b_reg.f(), tmx, reg_a, reg_b, size, size2, choice, aff_method, use_input ? 1 : 0, ftol, it_limit, 1, rec, stream);
             };
             const int reg_status = register_step(i, st, dev_reg, reg_records, out);
-            if (reg_status < 0) break;
+            if (reg_status == kAbandoned) break;
             if (!ok(reg_status, "registration", i, out)) break;
             if (fail_at.load() < (int)i) break;  // an earlier time point failed while this one registered: write nothing
             out("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",

@@ -94,3 +94,65 @@ extern "C" int mip3dgpu(float *, unsigned int *sizeMP, float *, unsigned int *s,
     sizeMP[0] = s[0]; sizeMP[1] = s[1]; sizeMP[2] = (unsigned)projectNum;
     return 0;
 }
+
+// ---- include/mil_device.h stage entries the tool's device-resident path calls: "device memory" is host memory here, every
+// stage is the stub of its libapi.h twin above, so the device path must write the host path's files byte for byte.
+#include "../../include/mil_device.h"
+
+namespace {
+thread_local int t_device = 0;
+}
+
+extern "C" int mil_set_device(int device) { t_device = device; return 0; }
+extern "C" int mil_dev_alloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); return *p ? 0 : -1; }
+extern "C" void mil_dev_free(void *p) { free(p); }
+extern "C" int mil_host_alloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); return *p ? 0 : -1; }
+extern "C" void mil_host_free(void *p) { free(p); }
+extern "C" int mil_stream_create(void **s) { *s = malloc(1); return 0; }
+extern "C" void mil_stream_destroy(void *s) { free(s); }
+extern "C" int mil_stream_sync(void *) { return 0; }
+extern "C" int mil_upload(void *d, const void *h, size_t bytes, void *) { std::memcpy(d, h, bytes); return 0; }
+extern "C" int mil_download(void *h, const void *d, size_t bytes, void *) { std::memcpy(h, d, bytes); return 0; }
+extern "C" int mil_u16_to_f32(float *o, const unsigned short *in, size_t n, void *) {
+    for (size_t i = 0; i < n; ++i) o[i] = (float)in[i];
+    return 0;
+}
+extern "C" int mil_f32_to_u16(unsigned short *o, const float *in, size_t n, void *) {
+    for (size_t i = 0; i < n; ++i) o[i] = (unsigned short)(long long)in[i];
+    return 0;
+}
+extern "C" int mil_imresize3d(float *o, const float *in, long long sx, long long sy, long long sz, long long sx2, long long sy2,
+                              long long sz2, void *) {
+    return imresize3d(o, const_cast<float *>(in), sx, sy, sz, sx2, sy2, sz2, t_device);
+}
+extern "C" int mil_rot_y90(float *o, const float *in, int nx, int ny, int nz, int direction, void *) {
+    unsigned int so[3], si[3] = {(unsigned)nx, (unsigned)ny, (unsigned)nz};
+    return imoperation3D(o, so, const_cast<float *>(in), si, direction == 1 ? 1 : 2, t_device);
+}
+extern "C" int mil_reg3d(float *d_reg, float *iTmx, const float *a, const float *b, const unsigned int *s1, const unsigned int *s2,
+                         int regChoice, int affMethod, int flagTmx, float ftol, int itLimit, int verbose, float *records, void *) {
+    return reg3d(d_reg, iTmx, const_cast<float *>(a), const_cast<float *>(b), const_cast<unsigned int *>(s1),
+                 const_cast<unsigned int *>(s2), regChoice, affMethod, flagTmx != 0, ftol, itLimit, t_device, -1, verbose != 0, records);
+}
+extern "C" int mil_decon_dualview(float *d, const float *a, const float *b, const unsigned int *size, const float *p1, const float *p2,
+                                  const unsigned int *psize, int constInit, int iters, int verbose, float *rec, int unmatch,
+                                  const float *bp1, const float *bp2, void *) {
+    return decon_dualview(d, const_cast<float *>(a), const_cast<float *>(b), const_cast<unsigned int *>(size), const_cast<float *>(p1),
+                          const_cast<float *>(p2), const_cast<unsigned int *>(psize), constInit != 0, iters, t_device, -1, verbose != 0, rec,
+                          unmatch != 0, const_cast<float *>(bp1), const_cast<float *>(bp2));
+}
+extern "C" int mil_max_projection(float *o, const float *in, int nx, int ny, int nz, int direction, void *) {
+    if (direction != 1) return 0;  // the host stub fills the Z projection only
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            float m = 0.f;
+            for (int z = 0; z < nz; ++z) m = std::fmax(m, in[x + (size_t)nx * (y + (size_t)ny * z)]);
+            o[x + (size_t)nx * y] = m;
+        }
+    return 0;
+}
+extern "C" int mil_mip3d(float *o, const float *, int nx, int ny, int, int, long long projectNum, int *size3, void *) {
+    size3[0] = nx; size3[1] = ny; size3[2] = (int)projectNum;
+    if (o) std::memset(o, 0, sizeof(float) * (size_t)nx * ny * projectNum);
+    return 0;
+}

@@ -84,19 +84,20 @@ def test_workers_reproduce_the_single_worker_run(tmp_path, tool, reg_mode):
     _series(tmp_path, n_points)
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
     trees = {}
-    for devices in ("0", "0,1", "2,0,1"):
-        out = tmp_path / f"out_{devices.replace(',', '_')}"
+    # the time point resident on the "device" (the default; "0" alone = two workers on one device) and the host-pointer path
+    for devices, path in (("0", "device"), ("0,1", "device"), ("2,0,1", "device"), ("0", "host"), ("1,0", "host")):
+        out = tmp_path / f"out_{path}_{devices.replace(',', '_')}"
         r = subprocess.run([tool] + _args(tmp_path, out, reg_mode, devices, n_points), capture_output=True, text=True,
-                           timeout=600, env=env)
-        assert r.returncode == 0, (devices, r.stdout[-1500:], r.stderr[-3000:])
+                           timeout=600, env=dict(env, MIL_BATCH_PATH=path))
+        assert r.returncode == 0, (devices, path, r.stdout[-1500:], r.stderr[-3000:])
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
-        trees[devices] = _tree(out)
+        trees[devices + " " + path] = _tree(out)
         log = open(out / "ProcessingLog.txt").read()
         seen = [int(line.split(":")[1]) for line in log.splitlines() if line.startswith("*** Image time point number")]
         want = list(range(n_points))
         assert seen == ([2] + want if reg_mode == 1 else want), (devices, seen)  # ordered whichever worker finished first
         assert "Batch processing completed" in log
-    one = trees["0"]
+    one = trees["0 host"]
     assert len(one) == 4 * n_points  # Decon_, Matrix_, MP_XY_ and RegB per time point
     for devices, t in trees.items():
         assert set(t) == set(one), devices
