@@ -32,6 +32,7 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -43,6 +44,8 @@ namespace {
 #include "fft_dev.h"
 
 constexpr int kNY = 512, kNZ = 256;  // the register yz kernel's y and z extents
+constexpr long long kStreamVolumeBytes = 48ll << 20;  // volumes from here on run the STREAM instantiations (see Aux): measured
+                                                      // +2 .. +7 % at 64 - 256 MB, +-1 % at 32 and at 512 MB (profiles/r05/nontemporal_streams.txt)
 // NH = nx / 2 spectrum columns (template parameter of every kernel): row pitch NH + 16 (ConvPlan: columns + 16), NH / 16
 // 16-column groups per row
 template <int NH>
@@ -57,23 +60,20 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
-// AUX: the cache-policy bits of the access (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt marks a stream -- data written
-// or read once by this kernel and next touched, from HBM anyway, by the following one (a spectrum is 268 MB).
-#ifndef MIL_AUX_ST_SPEC
-#define MIL_AUX_ST_SPEC 0
-#endif
-#ifndef MIL_AUX_ST_REAL
-#define MIL_AUX_ST_REAL 0
-#endif
-#ifndef MIL_AUX_LD_SPEC
-#define MIL_AUX_LD_SPEC 0
-#endif
-#ifndef MIL_AUX_LD_REAL
-#define MIL_AUX_LD_REAL 0
-#endif
-#ifndef MIL_AUX_LD_OTF
-#define MIL_AUX_LD_OTF 0
-#endif
+// Streams and the 256 MB Infinity Cache.  AUX = the cache-policy bits of a buffer access (gfx942 / gfx950: 1 = sc0, 2 = nt,
+// 16 = sc1).  An iteration moves ~3.5 GB through a memory-side cache of 256 MB; what profits from it is the SPECTRUM, written
+// by one kernel and read back by the next (268 MB at 512 x 512 x 256).  Everything touched once per iteration -- the OTFs, the
+// measured image, the estimate -- only pushes spectrum lines out, so in the STREAM instantiations of the register kernels those
+// accesses carry the non-temporal hint: 512 x 512 x 256 on one box 1 240 it/s without, 1 295 with the OTF and image / estimate
+// loads marked, 1 361 with the estimate's store marked too; marking the SPECTRUM instead loses 5-6 %
+// (profiles/r05/nontemporal_streams.txt).  Boxes whose whole working set fits the cache (volumes of a few ten MB) lose 4-7 %
+// with the hint -- their OTFs and images would have stayed -- so the host picks the instantiation by volume size
+// (ConvPlan::stream_, MIL_FX_STREAM=0 / 1 forces it).
+template <bool STREAM>
+struct Aux {
+    static constexpr int ld_spec = 0, st_spec = 0;
+    static constexpr int ld_otf = STREAM ? 2 : 0, ld_real = STREAM ? 2 : 0, st_real = STREAM ? 2 : 0;
+};
 template <int AUX = 0>
 __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX);
@@ -255,7 +255,7 @@ __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *til
 // per CU whose load / exchange / store phases overlap; the two halves of every 128-byte row segment go to workgroups t and
 // t + 8 -- the same XCD, a few dispatches apart -- so that HBM still sees whole lines (unpaired, the 64-byte segments cost
 // what the overlap gains: round 2).
-template <int NH, int COLS>
+template <int NH, int COLS, bool STREAM>
 __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
     static_assert(COLS == 16 || COLS == 8, "yz_conv_kernel: 16- or 8-column tiles");
     constexpr int THREADS = 32 * COLS;           // COLS columns x 8 rows x 4 z-residues
@@ -296,11 +296,11 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc)
-                    o[q & 1][kc * 4 + k] = buf_load2<MIL_AUX_LD_OTF>(ro, ovoff, ooff0 + (unsigned)((k * kGroups * kNZ + 64 * q + kc) * kW) * 8u);
+                    o[q & 1][kc * 4 + k] = buf_load2<Aux<STREAM>::ld_otf>(ro, ovoff, ooff0 + (unsigned)((k * kGroups * kNZ + 64 * q + kc) * kW) * 8u);
         };
         MIL_STAMP(0);
 #pragma unroll
-        for (int m = 0; m < 64; ++m) v[m] = buf_load2<MIL_AUX_LD_SPEC>(rs, voff, soff0 + m * zstep);
+        for (int m = 0; m < 64; ++m) v[m] = buf_load2<Aux<STREAM>::ld_spec>(rs, voff, soff0 + m * zstep);
         load_otf(0);
         load_otf(1);
         // ---- z forward, stages L = 256 (over j1) and L = 32 (over j2), in registers
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
         MIL_STAMP(4);
         if (g != 0 || col != 0) {  // the packed column belongs to the pair blocks below
 #pragma unroll
-            for (int m = 0; m < 64; ++m) buf_store2<MIL_AUX_ST_SPEC>(rs, voff, soff0 + m * zstep, v[m]);
+            for (int m = 0; m < 64; ++m) buf_store2<Aux<STREAM>::st_spec>(rs, voff, soff0 + m * zstep, v[m]);
         }
         MIL_STAMP(5);
 #ifdef MIL_FX_STAMPS
@@ -534,6 +534,8 @@ __global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const floa
                 const int idx = it0 + j * kYzThreads + tid;
                 const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
                 if (idx < PIECES)
+                    // no stream hint here: the boxes of this kernel are small enough for their OTFs to survive in the Infinity
+                    // Cache from one iteration to the next (hinted: -4 % at 64 MB volumes, profiles/r05/nontemporal_streams.txt)
                     v[j] = *reinterpret_cast<const float4 *>(a.otf + ((((long long)(T * b + row) * kGroups + g16) * NZ + kz) * kW) + c16 + 2 * q);
             }
 #pragma unroll
@@ -646,7 +648,7 @@ __device__ __forceinline__ float xy_div(float m, float t) {
     return q;
 }
 
-template <int MODE, int NY, int NH>
+template <int MODE, int NY, int NH, bool STREAM>
 __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
     constexpr int T = NY / 64;  // length of the y tail = distance between the rows of this workgroup
     constexpr int M = NH / 16;  // length of the LDS stage of the x transform
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
     const float2 wf = a.tw_x[kc];
     const float fc1 = odd ? -wf.x : wf.x, fc2 = wf.y, fh1 = 0.5f * fc1, fh2 = 0.5f * fc2;
 #pragma unroll
-    for (int m = 0; m < 64; ++m) v[m] = buf_load2<MIL_AUX_LD_SPEC>(rs, voff, soff0 + m * rstep);
+    for (int m = 0; m < 64; ++m) v[m] = buf_load2<Aux<STREAM>::ld_spec>(rs, voff, soff0 + m * rstep);
     // ---- y inverse head: DIT stages L = NY / 8 (over j2, m = j2 + 8 j1; element i = n2 of its sub-transform) and L = NY
     // (over j1; element i = n2 + T j2)
 #pragma unroll
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
         }
         // M / E of the first pass of the fused stage: in flight during the LDS stage (v[0..15] are free now)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pre[r] = buf_load2<MIL_AUX_LD_REAL>(rr, svoff, rsoff + r * srj);
+        for (int r = 0; r < 8; ++r) pre[r] = buf_load2<Aux<STREAM>::ld_real>(rr, svoff, rsoff + r * srj);
         if (grp == 0) MIL_STAMP(8);
         lds_barrier();
         if (grp == 0) MIL_STAMP(9);
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
             for (int r = 0; r < 8; ++r) mm[r] = pre[8 * ps + r];
             if (ps == 0) {  // the second pass's M / E
 #pragma unroll
-                for (int r = 0; r < 8; ++r) pre[8 + r] = buf_load2<MIL_AUX_LD_REAL>(rr, svoff, rsoff + spass + r * srj);
+                for (int r = 0; r < 8; ++r) pre[8 + r] = buf_load2<Aux<STREAM>::ld_real>(rr, svoff, rsoff + spass + r * srj);
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) t[c] = p[c * SCS];
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
                     float2 e = make_float2(m.x * t[j].x, m.y * t[j].y);
                     e.x = (e.x > a.eps) ? e.x : a.eps;
                     e.y = (e.y > a.eps) ? e.y : a.eps;
-                    buf_store2<MIL_AUX_ST_REAL>(rr, svoff, rsoff + ps * spass + j * srj, e);
+                    buf_store2<Aux<STREAM>::st_real>(rr, svoff, rsoff + ps * spass + j * srj, e);
                     t[j] = e;
                 }
             }
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
     }
     MIL_STAMP(4);
 #pragma unroll
-    for (int m = 0; m < 64; ++m) buf_store2<MIL_AUX_ST_SPEC>(rs, voff, soff0 + m * rstep, v[m]);
+    for (int m = 0; m < 64; ++m) buf_store2<Aux<STREAM>::st_spec>(rs, voff, soff0 + m * rstep, v[m]);
     MIL_STAMP(5);
 #ifdef MIL_FX_STAMPS
     if (a.stamps) {
@@ -943,6 +945,10 @@ void ConvPlan::init_two_pass() {
     pairs_.alloc(pairs.size());
     MIL_HIP(hipMemcpy(pairs_.get(), pairs.data(), pairs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     two_pass_ = true;
+    // non-temporal hints on the once-per-iteration streams (Aux<STREAM>) where the working set -- two OTFs, image, estimate,
+    // spectrum: five volumes -- is far beyond the 256 MB Infinity Cache; MIL_FX_STREAM=0 / 1 forces the choice
+    stream_ = box_.count() * 4 >= kStreamVolumeBytes;
+    if (const char *e = getenv("MIL_FX_STREAM")) stream_ = e[0] == '1';
 }
 
 namespace {
@@ -999,7 +1005,8 @@ void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
         constexpr int NH = decltype(nh_tag)::value;
 #define MIL_YZ(NY, NZ, COLS, PAIR) \
     else if (ny == NY && nz == NZ) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ, NH, COLS, PAIR>), grid_for(COLS), block, 0, s, a, twz);
-        if (ny == kNY && nz == kNZ) hipLaunchKernelGGL((yz_conv_kernel<NH, 8>), grid_for(8), dim3(256), 0, s, a);
+        if (ny == kNY && nz == kNZ && stream_) hipLaunchKernelGGL((yz_conv_kernel<NH, 8, true>), grid_for(8), dim3(256), 0, s, a);
+        else if (ny == kNY && nz == kNZ) hipLaunchKernelGGL((yz_conv_kernel<NH, 8, false>), grid_for(8), dim3(256), 0, s, a);
         MIL_YZ(1024, 128, 8, true)
         MIL_YZ(1024, 64, 8, true)
         MIL_YZ(512, 128, 8, true)
@@ -1031,17 +1038,24 @@ void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float ep
     with_nh(box_.nx, [&](auto nh_tag) {
         constexpr int NH = decltype(nh_tag)::value;
         const dim3 block(NH);
-#define MIL_XY(NY)                                                                                               \
+#define MIL_XY_S(NY, STREAM)                                                                                     \
     switch (mode) {                                                                                              \
-        case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio, NY, NH>), grid, block, 0, s, a); break;             \
-        case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate, NY, NH>), grid, block, 0, s, a); break;           \
-        default: hipLaunchKernelGGL((xy_kernel<kXUpdateLast, NY, NH>), grid, block, 0, s, a); break;             \
+        case kXRatio: hipLaunchKernelGGL((xy_kernel<kXRatio, NY, NH, STREAM>), grid, block, 0, s, a); break;     \
+        case kXUpdate: hipLaunchKernelGGL((xy_kernel<kXUpdate, NY, NH, STREAM>), grid, block, 0, s, a); break;   \
+        default: hipLaunchKernelGGL((xy_kernel<kXUpdateLast, NY, NH, STREAM>), grid, block, 0, s, a); break;     \
+    }
+#define MIL_XY(NY)                 \
+    if (stream_) {                 \
+        MIL_XY_S(NY, true)         \
+    } else {                       \
+        MIL_XY_S(NY, false)        \
     }
         if (box_.ny == 1024) { MIL_XY(1024) }
         else if (box_.ny == 512) { MIL_XY(512) }
         else if (box_.ny == 256) { MIL_XY(256) }
         else { MIL_XY(128) }
 #undef MIL_XY
+#undef MIL_XY_S
     });
     MIL_HIP(hipGetLastError());
 }

@@ -13,6 +13,7 @@ constexpr int kWP = 17;   // LDS row stride in float2
 constexpr int kNT = 256;  // threads per workgroup
 constexpr int kBatch = 8; // float4 loads in flight per lane while staging
 
+
 // Written on the 2-vectors themselves: v_pk_add/mul/fma_f32 without relying on the SLP vectoriser (csrc/fft2p.hip is built
 // without it), 35 % fewer vector instructions in a radix-8 butterfly than component by component.
 __device__ __forceinline__ float2 c_add(float2 a, float2 b) { return a + b; }

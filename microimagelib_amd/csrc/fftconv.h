@@ -83,6 +83,7 @@ private:
     DeviceBuffer<unsigned short> neg_y_, neg_z_;    // position holding the negated frequency of position p
     void init_two_pass();
     bool two_pass_ = false;
+    bool stream_ = false;  // fft2p.hip: non-temporal hints on OTF / image / estimate accesses (large boxes)
     DeviceBuffer<unsigned short> pairs_;  // two-pass path: pairs of 8-row blocks holding ky and -ky
     int n_pairs_ = 0;
 };
