@@ -179,6 +179,10 @@ int mil_corr_sums_padded(const float *d_target, const mil_padded_source *src, in
  * -1 (default) chooses per matrix.  Kernels 0-5 return the same bits; kernels 6-10 sum the same float32 voxel values in
  * another order (equal to ~1e-15 relative, bit-reproducible from run to run on one device). */
 int mil_corr_padded_force_kernel(int kernel);
+/* diagnostics (process-wide): release / acquire fences around the cost kernels' completion counters (1 / 0; -1: back to
+ * MIL_CORR_FENCES, which is read once), and the workgroups per compute unit of the chunked cost kernels (0: built-in) */
+int mil_corr_set_fences(int on);
+int mil_corr_set_chunk_wgs_per_cu(int n);
 /* host logic only (no GPU needed): the LAYOUT the per-matrix choice takes for m12 -- 0 plain + plane reuse, 1 row pairs,
  * 2 row pairs + plane reuse (the one-voxel kernels; what runs when the target width is not a multiple of 128) */
 int mil_corr_padded_pick_kernel(const float *m12);

@@ -116,6 +116,8 @@ SIGNATURES = {
     "mil_reg3d_trace_begin": (C.c_int, [C.c_int]),
     "mil_reg3d_trace_read": (C.c_int, [c_float_p, C.c_int]),
     "mil_corr_padded_force_kernel": (C.c_int, [C.c_int]),
+    "mil_corr_set_fences": (C.c_int, [C.c_int]),
+    "mil_corr_set_chunk_wgs_per_cu": (C.c_int, [C.c_int]),
     "mil_corr_padded_pick_kernel": (C.c_int, [c_float_p]),
     "mil_corr_padded_pick_kernel2": (C.c_int, [c_float_p, C.c_int]),
     "mil_padded_source_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int] * 3 + [C.c_void_p]),

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlockThreads) void corr_kernel(const float *__rest
             if (tx > 0 && tx < (float)a.sx && ty > 0 && ty < (float)a.sy && tz > 0 && tz < (float)a.sz)
                 sv = CACHE ? fetch_linear_cached(src, a.sx, a.sy, a.sz, tx, ty, tz, pc, a.wq)
                            : fetch_linear(src, a.sx, a.sy, a.sz, tx, ty, tz, a.wq);
-            const float tv = *tp;
+            const float tv = __builtin_nontemporal_load(tp);  // read once per evaluation: leave the Infinity Cache to the source (corr_padded.hip)
             if (FLOAT_PRODUCTS) {
                 const float q = sv * sv, c = tv * sv;
                 ss += (double)q;
@@ -231,6 +231,7 @@ AffineArgs make_args(Dims t, Dims s, const Affine12 &m) {
 }
 
 std::atomic<int> g_weight_bits{-1};  // -1: not set through the API, MIL_TEX_WEIGHT_BITS decides
+std::atomic<int> g_corr_fences{-1};  // -1: MIL_CORR_FENCES (read once) decides
 
 }  // namespace
 
@@ -251,6 +252,16 @@ int texture_weight_bits() {
     const char *e = getenv("MIL_TEX_WEIGHT_BITS");
     return (e && atoi(e) == 8) ? 8 : 0;
 }
+// MIL_CORR_FENCES=1 / corr_set_fences(1): release / acquire fences around the completion counters of the cost kernels (a
+// diagnostic, csrc/corr_finish.h).  No getenv on the evaluation path: a registration makes ~2 000 of them back to back.
+bool corr_fences() {
+    const int v = g_corr_fences.load(std::memory_order_relaxed);
+    if (v >= 0) return v != 0;
+    static const bool env = getenv("MIL_CORR_FENCES") && getenv("MIL_CORR_FENCES")[0] == '1';
+    return env;
+}
+void corr_set_fences(int on) { g_corr_fences.store(on < 0 ? -1 : (on ? 1 : 0)); }
+
 void set_texture_weight_bits(int bits) { g_weight_bits.store(bits == 8 ? 8 : bits == 0 ? 0 : -1); }
 
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s,
@@ -317,8 +328,7 @@ CorrTail CorrWorkspace::next(size_t nblocks, hipStream_t s) {
     }
     if (partials.size() < 2 * nblocks + 2 * kCorrCounters) partials.alloc(2 * nblocks + 2 * kCorrCounters);
     ticket += 1.0;
-    const char *f = getenv("MIL_CORR_FENCES");  // read per evaluation: the tests flip it within one process
-    return CorrTail{partials.get(), (int)nblocks, counter.get(), host, ticket, (f && f[0] == '1') ? 1 : 0};
+    return CorrTail{partials.get(), (int)nblocks, counter.get(), host, ticket, corr_fences() ? 1 : 0};
 }
 
 void CorrWorkspace::wait(hipStream_t s) {

@@ -358,6 +358,14 @@ int mil_corr_padded_pick_kernel2(const float *m12, int wide) {
     std::memcpy(m.m, m12, sizeof m.m);
     return k::corr_padded_pick_kernel(m, wide != 0);
 }
+int mil_corr_set_fences(int on) {
+    k::corr_set_fences(on);
+    return 0;
+}
+int mil_corr_set_chunk_wgs_per_cu(int n) {
+    k::corr_set_chunk_wgs_per_cu(n);
+    return 0;
+}
 int mil_corr_padded_force_kernel(int kernel) {
     k::corr_padded_force_kernel(kernel);
     return 0;

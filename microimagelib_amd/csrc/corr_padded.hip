@@ -62,6 +62,14 @@ __device__ __forceinline__ void corr_tile_of_block(int gx, int gy, int &bx, int 
     bz = (int)(rest / (unsigned)gy);
 }
 
+// The target is read ONCE per evaluation, the source 2-4 times per voxel (and again by the next of the ~2 000 evaluations of
+// a registration): the target's loads carry the non-temporal hint, so that the 256 MB Infinity Cache is left to the source
+// (271 MB padded at 512 x 512 x 256) instead of being swept by 540 MB per evaluation: -8 .. -10 % per evaluation for every
+// kernel and matrix class (profiles/r05/reg_cost_target_nontemporal.txt; the hint on the GATHERS instead: +20 .. +50 %).
+__device__ __forceinline__ float target_load(const char *base, unsigned offset) {
+    return __builtin_nontemporal_load(reinterpret_cast<const float *>(base + offset));
+}
+
 // (lo, hi) = two adjacent source voxels; address = base + voffset (per lane) + soffset (uniform)
 __device__ __forceinline__ f32x2 gather_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffset, (int)soffset, 0);
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void corr_padded_kernel(const float *__re
             const unsigned off = (unsigned)(__mul24((int)fz, a.plane4) + __mul24((int)fy, a.row4) + a.origin4) +
                                  ((unsigned)(int)fx << 2);
             p.off = p.in ? off : 0u;
-            p.tv = *reinterpret_cast<const float *>(tbase + toff);
+            p.tv = target_load(tbase, toff);
             return p;
         };
         // lo = rows (y0, y1) of the lower source plane, up = of the upper one; the reference's interpolation order
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void corr_rowpair_kernel(const float *__r
             const unsigned off = (unsigned)(__mul24((int)fz, a.plane4) + __mul24((int)fy, a.row4) + a.origin4) +
                                  ((unsigned)(int)fx << 3);
             p.off = p.in ? off : 0u;
-            p.tv = *reinterpret_cast<const float *>(tbase + toff);
+            p.tv = target_load(tbase, toff);
             return p;
         };
         auto accumulate = [&](const Step &p, f32x4 lo, f32x4 up) {
@@ -445,8 +453,8 @@ __device__ __forceinline__ void corr_pair_body(const float *__restrict__ tgt, co
                 A.off = A.in ? A.off : 0u;
                 B.off = B.in ? B.off : 0u;
             }
-            A.tv = *reinterpret_cast<const float *>(tbase + toff);
-            B.tv = *reinterpret_cast<const float *>(tbase + toff + 4u * kTileX);
+            A.tv = target_load(tbase, toff);
+            B.tv = target_load(tbase, toff + 4u * kTileX);
         };
         auto finish = [&](const Vox &p, float r, double &ss, double &st) {
             const float sv = CHECK ? __uint_as_float(p.in ? __float_as_uint(r) : 0u) : r;
@@ -734,8 +742,8 @@ __global__ __launch_bounds__(kThreads, CHUNK_WAVES) void corr_chunk_kernel(const
                 A.off = A.in ? A.off : (ride ? pA.off + sStep : 0u);
                 B.off = B.in ? B.off : (ride ? pB.off + sStep : 0u);
             }
-            A.tv = *reinterpret_cast<const float *>(tbase + toff);
-            B.tv = *reinterpret_cast<const float *>(tbase + toff + 4u * kTileX);
+            A.tv = target_load(tbase, toff);
+            B.tv = target_load(tbase, toff + 4u * kTileX);
         };
         auto finish = [&](const Vox &p, float r, double &ss, double &st) {
             const float sv = __uint_as_float(p.in ? __float_as_uint(r) : 0u);
@@ -961,6 +969,7 @@ namespace {
 //   < 0.05  plain layout + plane reuse           (translations, pure scales, rotations up to ~1 degree)
 //   < 2.0   row pairs + plane reuse              (the usual registration matrix: a few degrees AND a few per cent)
 //   else    row pairs, both planes gathered      (large rotations)
+std::atomic<int> g_chunk_wgs_per_cu{0};  // corr_set_chunk_wgs_per_cu (experiments); 0: kChunkWgsPerCu
 std::atomic<int> g_forced_kernel{-1};  // test / profiling aid (process-wide), corr_padded_force_kernel(): 0-2 one voxel per lane, 3-5 two, 6 two + marching along y
 
 // Expected number of wave-wide re-gathers per step when a wave of 64 consecutive x marches along z / along y (see the
@@ -1040,8 +1049,9 @@ template <typename K>
 unsigned chunk_grid(K kernel, int which, unsigned long long total_steps) {
     struct PerDevice { int cus = 0, per_cu = 0; };
     static PerDevice cache[4][64];  // by kernel and device; filled on first use (benign race: same values)
-    int dev = 0;
-    MIL_HIP(hipGetDevice(&dev));
+    static thread_local int dev = -1;  // the device of this host thread's evaluations (a thread registers on one device)
+    static thread_local int dev_checked = 0;
+    if (dev < 0 || (++dev_checked & 1023) == 0) MIL_HIP(hipGetDevice(&dev));
     PerDevice &pd = cache[which & 3][dev & 63];
     if (pd.cus == 0) {
         int cus = 0, per_cu = 0;
@@ -1051,7 +1061,7 @@ unsigned chunk_grid(K kernel, int which, unsigned long long total_steps) {
         pd.cus = std::max(cus, 1);
     }
     int per_cu = std::min(pd.per_cu, kChunkWgsPerCu[which & 3]);
-    if (const char *e = getenv("MIL_CORR_CHUNK_WGS_PER_CU")) per_cu = std::max(1, atoi(e));  // experiments: read per call
+    if (const int forced = g_chunk_wgs_per_cu.load(std::memory_order_relaxed)) per_cu = forced;  // experiments
     const unsigned long long want = (unsigned long long)pd.cus * per_cu;
     const unsigned long long most = (total_steps + kMinChunk - 1) / kMinChunk;
     return (unsigned)std::max(1ull, std::min(want, most));
@@ -1069,6 +1079,7 @@ int magic_origin(int origin4, int row4, int plane4, int shift) {
 }  // namespace
 
 void corr_padded_force_kernel(int kernel) { g_forced_kernel = kernel; }
+void corr_set_chunk_wgs_per_cu(int n) { g_chunk_wgs_per_cu = n > 0 ? n : 0; }
 
 int corr_padded_pick_kernel(const Affine12 &m, bool wide) {
     return wide ? pick_kernel(m.m, true, true) : pick_layout(m.m, true);

@@ -82,6 +82,9 @@ struct Affine12 {
 // registration evaluates its cost with the general kernel (the padded-source kernels implement exact weights only).
 int texture_weight_bits();
 void set_texture_weight_bits(int bits);  // 0 | 8 | anything else: back to the environment's choice
+bool corr_fences();
+void corr_set_fences(int on);           // 1 / 0; -1: back to MIL_CORR_FENCES
+void corr_set_chunk_wgs_per_cu(int n);  // experiments: workgroups per CU of the chunked cost kernels (0: the built-in choice)
 // out[x,y,z] = trilinear(src, M*(x,y,z,1)) inside the window, 0 outside.
 // strict_window: lower bound 0 < t instead of 0 <= t (the reference's 2-D transform kernel).
 void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m,

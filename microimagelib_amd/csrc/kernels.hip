@@ -302,8 +302,9 @@ __global__ void pad_stack_kernel(float *__restrict__ out, const float *__restric
     int ix = clampi(x - g.ox, 0, g.sx - 1);
     int iy = clampi(y - g.oy, 0, g.sy - 1);
     int iz = clampi(z - g.oz, 0, g.sz - 1);
-    out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] =
-        in[(size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)];
+    // one pass, nothing re-read: non-temporal on both sides (the 256 MB Infinity Cache keeps what the next kernel wants)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(in + (size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)),
+                                out + (size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z));
 }
 
 // cropgpukernel :740-753 (g.f* = cropped output box, g.s* = big input box).
@@ -312,8 +313,8 @@ __global__ void crop_kernel(float *__restrict__ out, const float *__restrict__ i
     if (!out_xyz(g, x, y, z)) return;
     int ix = x + g.ox, iy = y + g.oy, iz = z + g.oz;
     if (ix < g.sx && iy < g.sy && iz < g.sz)
-        out[(size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)] =
-            in[(size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)];
+        __builtin_nontemporal_store(__builtin_nontemporal_load(in + (size_t)ix + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz)),
+                                    out + (size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z));
 }
 
 // alignsize3Dgpukernel :755-769.
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void rot_y90_kernel(float *__restrict__ out, c
 #pragma unroll 4
     for (int kk = w; kk < 64; kk += 4) {
         const int i = i0 + lane, k = k0 + kk;
-        if (i < g.sx && k < g.sz) tile[kk][lane] = in[(size_t)i + (size_t)g.sx * ((size_t)j + (size_t)g.sy * k)];
+        if (i < g.sx && k < g.sz) tile[kk][lane] = __builtin_nontemporal_load(in + (size_t)i + (size_t)g.sx * ((size_t)j + (size_t)g.sy * k));
     }
     __syncthreads();
 #pragma unroll 4
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void rot_y90_kernel(float *__restrict__ out, c
         const int i = i0 + ii, k = k0 + lane;
         if (i < g.sx && k < g.sz) {
             const int ox = direction == 1 ? k : g.sz - 1 - k, oz = direction == 1 ? g.sx - 1 - i : i;
-            out[(size_t)ox + (size_t)g.fx * ((size_t)j + (size_t)g.fy * oz)] = tile[lane][ii];
+            __builtin_nontemporal_store(tile[lane][ii], out + (size_t)ox + (size_t)g.fx * ((size_t)j + (size_t)g.fy * oz));
         }
     }
 }

@@ -176,6 +176,17 @@ def corr_padded_force_kernel(kernel: int = -1):
     _lib.load().mil_corr_padded_force_kernel(int(kernel))
 
 
+def corr_set_fences(on: int = -1):
+    """Diagnostic: 1 adds release / acquire fences around the cost kernels' completion counters, 0 removes them, -1 returns
+    control to MIL_CORR_FENCES (read once per process)."""
+    _lib.load().mil_corr_set_fences(int(on))
+
+
+def corr_set_chunk_wgs_per_cu(n: int = 0):
+    """Experiments: workgroups per compute unit of the chunked cost kernels (0 = the library's choice)."""
+    _lib.load().mil_corr_set_chunk_wgs_per_cu(int(n))
+
+
 def corr_sums(target: torch.Tensor, src, m12, stream=None):
     m = np.ascontiguousarray(m12, dtype=np.float32).reshape(12)
     out = (C.c_double * 2)()

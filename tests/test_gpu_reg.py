@@ -612,15 +612,15 @@ def test_fenced_and_fence_free_tails_agree(dev, monkeypatch):
     for kern in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
         dev.corr_padded_force_kernel(kern)
         for m in (ident, rot):
-            monkeypatch.delenv("MIL_CORR_FENCES", raising=False)
+            dev.corr_set_fences(0)
             free = [dev.corr_sums(tgt, pad, m) for _ in range(3)]
-            monkeypatch.setenv("MIL_CORR_FENCES", "1")
+            dev.corr_set_fences(1)
             fenced = [dev.corr_sums(tgt, pad, m) for _ in range(3)]
             assert len(set(free + fenced)) == 1, (kern, free, fenced)
     dev.corr_padded_force_kernel(-1)
-    monkeypatch.setenv("MIL_CORR_FENCES", "1")
+    dev.corr_set_fences(1)
     a = dev.corr_sums(tgt, vol, rot)  # the general kernel (csrc/affine.hip) shares the tail
-    monkeypatch.delenv("MIL_CORR_FENCES")
+    dev.corr_set_fences(-1)
     assert dev.corr_sums(tgt, vol, rot) == a
     assert _same_sums(dev.corr_sums(tgt, pad, rot), a, -1)
     pad.close()

@@ -44,10 +44,7 @@ ref = {name: mdev.corr_sums(tgt, pad, m) for name, m in cases}
 
 
 def run(kern, per_cu):
-    if per_cu is None:
-        os.environ.pop("MIL_CORR_CHUNK_WGS_PER_CU", None)
-    else:
-        os.environ["MIL_CORR_CHUNK_WGS_PER_CU"] = str(per_cu)
+    mdev.corr_set_chunk_wgs_per_cu(per_cu or 0)
     mdev.corr_padded_force_kernel(kern)
     out = []
     for name, m in cases:
