@@ -733,12 +733,15 @@ def main():
         # DESIGN.md "Kernels").  Fused backend: every family is one hand-written kernel.
         two_pass = fused and getattr(eng, "two_pass", 0) == 3
         if two_pass:  # csrc/fft2p.hip: the y transform rides in the z kernel (its last stage) and in the x kernel
+            # the spectra and OTFs of this path are PACKED: exactly nx / 2 complex columns per row (column 0 carries X[0] and
+            # X[nx/2]), C'' = 8 nz ny nx / 2 = R bytes -- what the kernels really have to move
+            C2 = 8 * SHAPE[0] * SHAPE[1] * (SHAPE[2] // 2)
             fam = {
-                "xy_update (y head^-1, x^-1, E=max(E*T,0.01), x, y head fused)": (upd_ms, upd_n, 2 * C + 2 * R),
-                "xy_ratio (y head^-1, x^-1, T=A/T, x, y head fused)": (rat_ms, rat_n, 2 * C + R),
-                "yz_conv (y tail, z, *OTF, z^-1, y tail^-1 fused)": (cm_ms, cm_n, 3 * C),
+                "xy_update (y head^-1, x^-1, E=max(E*T,0.01), x, y head fused)": (upd_ms, upd_n, 2 * C2 + 2 * R),
+                "xy_ratio (y head^-1, x^-1, T=A/T, x, y head fused)": (rat_ms, rat_n, 2 * C2 + R),
+                "yz_conv (y tail, z, *OTF, z^-1, y tail^-1 fused)": (cm_ms, cm_n, 3 * C2),
             }
-            iter_bytes = 10 * C + 3 * R
+            iter_bytes = 10 * C2 + 3 * R
         elif fused:
             fam = {
                 "x_update (x^-1, E=max(E*T,0.01), x fused)": (upd_ms, upd_n, 2 * C + 2 * R),

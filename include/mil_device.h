@@ -57,6 +57,9 @@ int mil_align_size(float *d_out, const float *d_in, int ox, int oy, int oz, int 
 int mil_flip3(float *d_out, const float *d_in, int nx, int ny, int nz, void *stream);                             /* flipgpu :1680 */
 int mil_rot_y90(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream);            /* rotbyyaxis :528 */
 int mil_max_projection(float *d_out, const float *d_in, int nx, int ny, int nz, int direction, void *stream);     /* maxprojection :490 */
+/* Projections (mil_max_projection, mil_mip3d, mil_resample_mip_z) assume finite, NaN-free volumes: the reference's sequential
+ * `a = a > v ? a : v` is order dependent on NaN (a NaN wipes the running maximum and survives only as a column's last sample),
+ * which the segmented maxima here do not reproduce. */
 /* mip3dgpu (src/apifunc.cpp:576-644) on device memory: projectNum rotations about x (rAxis 1) or y (2), each resampled into the
  * rotated box and projected along z; d_out receives [projectNum][size3[1]][size3[0]] floats.  d_out == NULL only reports
  * size3 = {width, height, projectNum}.  Synchronises `stream` before it returns. */

@@ -296,8 +296,10 @@ int main(int argc, char **argv) {
         cli::Volume *a = nullptr, *b = nullptr;
     };
     // index of the first time point that failed (INT_MAX: none).  The batch stops WHERE THE REFERENCE STOPS: time points before
-    // it are completed by whichever worker owns them, time points after it are not started (one in flight is abandoned before
-    // it writes anything).
+    // it are completed by whichever worker owns them, time points after it are not started.  One in flight when the failure
+    // happens is abandoned at its next stage boundary -- before its matrix file if it is still registering, before its
+    // deconvolved stack if it is deconvolving; a later time point that had already written its matrix (or, past the
+    // deconvolution, its stack and projections) keeps what it wrote.
     std::atomic<int> fail_at{INT_MAX};
     auto preprocess = [&](Prepared &p, int dev) -> bool {
         cli::Volume &a_in = p.in.first, &b_in = p.in.second;
@@ -518,6 +520,7 @@ int main(int argc, char **argv) {
                 stop((int)i);
                 break;
             }
+            if (fail_at.load() < (int)i) break;  // an earlier time point failed meanwhile: nothing more of this one is written
             out("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
                 decon_records[5]);
             if (behind.valid()) behind.get();  // the previous stack has left decon_out

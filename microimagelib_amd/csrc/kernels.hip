@@ -369,7 +369,12 @@ __global__ __launch_bounds__(256) void rot_y90_kernel(float *__restrict__ out, c
 //   dir 1  along z: image [sy][sx]          thread = (x, y), loop over z
 //   dir 2  along y: image [sx][sz] (w = sz) thread = (x, z), loop over y; the (small) output is written strided
 //   dir 3  along x: image [sz][sy] (w = sy) one wave per volume row, lanes stride x, wave-level maximum
-// max is exact and order-independent on the data these see (no NaN), so the tree of dir 3 returns the reference's value.
+// max is exact and order-independent on NaN-free data, so the tree of dir 3 and the segments of dir 1 / 2 (published through
+// an integer atomic max on positive values) return the reference's value.  PRECONDITION: finite, NaN-free volumes.  The
+// reference's sequential `a = a > v ? a : v` lets a NaN wipe the running maximum and survive only as the LAST sample of a
+// column; a segmented maximum cannot reproduce that order dependence (a NaN segment maximum is never published here), so on
+// NaN input the planes differ from the reference's -- the same holds for the fused resample + projection kernels
+// (affine.hip, resample_march.hip).  A deconvolution that has diverged to NaN shows up in the stack, not in its MIPs.
 __global__ void max_projection_kernel(float *__restrict__ out, const float *__restrict__ in, int sx, int sy, int sz,
                                       int dir) {
     const size_t zs = (size_t)sx * sy;
