@@ -150,5 +150,40 @@ __device__ __forceinline__ void corr_publish_as(int b, double a0, double a1, Cor
     }
 }
 
+// The chunked kernels publish at most a few thousand partials (one per resident workgroup): the workgroup that finishes last
+// sums ALL of them itself -- thread-strided, then waves, then thread 0: a fixed order -- instead of the group sums of
+// corr_publish_as.  The COUNT stays two-level (kCorrCounters group counters + one on top: 1 536 workgroups finishing within a
+// few microseconds on one counter would queue at the memory-side atomic unit), the SUM loses a store -> wait -> count round
+// trip: ~2 us less between the last workgroup's last step and the ticket.
+template <int THREADS>
+__device__ __forceinline__ void corr_publish_flat(int b, double a0, double a1, CorrTail t, double *lds, int *flag) {
+    __syncthreads();
+    const int groups = t.nblocks < kCorrCounters ? t.nblocks : kCorrCounters;
+    const int grp = b % groups;
+    const int members = (t.nblocks - grp + groups - 1) / groups;
+    if (threadIdx.x == 0) {
+        corr_store_agent(t.partials + b, a0);
+        corr_store_agent(t.partials + t.nblocks + b, a1);
+        corr_stores_done();
+        if (t.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        bool last = corr_count(t.counter + grp) == (unsigned)members - 1u;
+        if (last) last = corr_count(t.counter + kCorrCounters) == (unsigned)groups - 1u;
+        if (t.fenced && last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    double r0, r1;
+    corr_block_sum<THREADS>(t.partials, t.partials + t.nblocks, t.nblocks, 1, lds, r0, r1);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i <= kCorrCounters; ++i)
+            __hip_atomic_store(t.counter + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(t.host + 0, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(t.host + 1, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        corr_stores_done();  // the sums are in host memory before the ticket that announces them
+        __hip_atomic_store(t.host + 2, t.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace k
 }  // namespace mil

@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kThreads, CHUNK_WAVES) void corr_chunk_kernel(const
             v1 += lds[kTileY + w];
         }
     }
-    corr_publish_as<kThreads>((int)blockIdx.x, v0, v1, tail, lds, &last);
+    corr_publish_flat<kThreads>((int)blockIdx.x, v0, v1, tail, lds, &last);
 }
 
 // dst[z+1][y+1][x+1] = (src[z][y][x], src[z][y+1][x]) with edge replication; y runs over [-1, sy-1].
