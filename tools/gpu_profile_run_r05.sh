@@ -15,8 +15,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $B5 > $out/prof_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $B5 > $out/prof_write.log 2>&1
 find $out -size +20M -delete
-python tools/rocprof_summary.py $out $out/summary > $out/summary.log 2>&1   # also refreshes profiles/pmc_traffic.json in this copy
-cp profiles/pmc_traffic.json $out/pmc_traffic.json
+python tools/rocprof_summary.py $out $out/summary > $out/summary.log 2>&1   # writes $out/pmc_traffic.json (-> profiles/pmc_traffic.json)
 timeout 900 python bench.py > $out/bench.json 2> $out/bench.err
 timeout 600 python bench.py --steps 20 --no-cpu-baseline > $out/bench_steps20.json 2> $out/bench_steps20.err
 timeout 300 python bench.py --no-cpu-baseline --no-extra --backend rocfft > $out/bench_rocfft_backend.json 2> $out/bench_rocfft.err
