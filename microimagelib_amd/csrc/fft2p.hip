@@ -13,21 +13,23 @@
 // twiddles and the OTF tiling are exactly those of the classic kernels (same in-place digit-reversed order), so both
 // paths share OTFs and can be mixed stage by stage (MIL_FX_TWOPASS, tests/test_gpu_fft.py).
 //
-// Boxes.  nx = 256, 512, 1024 (NH = nx / 2 = 128, 256, 512 spectrum columns: the xy kernel gives every column a thread
-// and runs its x transform as NH = 16 x M: an LDS stage of length M = NH / 16 and a radix-16 stage in registers, fused with
-// the real-space operation).  Every column length of this library
-// starts its in-place transform with TWO radix-8 stages (fft_dev.h, pick_radix), so for any ny the "head" is 64 rows
-// y = n2 + T m (T = ny / 64) and the "tail" a transform of length T over T ADJACENT rows:
-//   xy_kernel<MODE, NY>      NY = 1024, 512, 256, 128 (T = 16, 8, 4, 2): 64 rows of one plane per thread; does not care about z
-//   yz_conv_kernel           ny = 512, nz = 256: register tiles of 8 rows x 8 columns x all z, two workgroups per CU
-//   yz_lds_kernel<NY, NZ>    the tile of T rows x 8 (16 for the smallest boxes) columns x all z FITS the LDS (T x nz <= 1024) and
-//                            the same sequence runs on the classic LDS stage code
-// The 8-column tiles are dealt so that the two halves of a 128-byte row segment land on the same XCD (yz_conv, host side).
-// => {256, 512, 1024} x {1024, 512, 256, 128} x {64, 128, 256} (x, y, z) without ... x 1024 x 256, and ... x 128 x 512:
-// 36 boxes.
+// Boxes.  Every column length of this library starts its in-place transform with TWO radix-8 stages (fft_dev.h, pick_radix),
+// so for any ny = 64 T the "head" is 64 rows y = n2 + T m and the "tail" a transform of length T over T ADJACENT rows (one or
+// two small stages, primes 3 .. 13 included); the xy kernel gives every spectrum column a thread and runs its x transform as
+// NH = nx / 2 = 16 x M: LDS stage(s) of length M and a radix-16 stage in registers, fused with the real-space operation.
+//   xy_kernel<MODE, NY, NH>   this file: nx = 256, 512, 1024 and ny = 128 .. 1024 in powers of two, as compile-time constants;
+//                             fft2p_any_xy.hip: every nx = 192 .. 1024 and ny = 128 .. 1024 in multiples of 64 (the sizes
+//                             snapTransformSize produces, reference src/api_subfunc.cu:57-87), ny a run-time argument
+//   yz_conv_kernel            this file: ny = 512, nz = 256 -- register tiles of 8 rows x 8 columns x all z, two workgroups per CU
+//   yz_lds_kernel<NY, NZ>     fft2p_any_yz.hip: the tile of T rows x 4 / 8 / 16 columns x all z FITS the LDS (T x nz <= 2048) and
+//                             the same sequence runs on the classic LDS stage code; any nx
+// The narrow tiles are dealt so that the pieces of a 128-byte row segment land on the same XCD.
+// => nx = 192 .. 1024, ny = 128 .. 1024, nz = 64 .. 1024 in multiples of 64 with (ny / 64) x nz <= 2048, plus ... x 512 x 256 for
+// nx = 256, 512, 1024.  Larger yz tiles (384 x 384 x 384, 512 x 512 x 512 ...) keep the classic sequence.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "fft2p.hip is written for gfx950 (v_permlane32_swap, 160 KB of LDS per workgroup): build with --offload-arch=gfx950"
 #endif
+#include "fft2p_any.h"
 #include "fftconv.h"
 
 #include <cstddef>
@@ -41,876 +43,30 @@ namespace fx {
 
 namespace {
 
-#include "fft_dev.h"
-
-constexpr int kNY = 512, kNZ = 256;  // the register yz kernel's y and z extents
-constexpr long long kStreamVolumeBytes = 48ll << 20;  // volumes from here on run the STREAM instantiations (see Aux): measured
-                                                      // +2 .. +7 % at 64 - 256 MB, +-1 % at 32 and at 512 MB (profiles/r05/nontemporal_streams.txt)
-// NH = nx / 2 spectrum columns (template parameter of every kernel): row pitch NH + 16 (ConvPlan: columns + 16), NH / 16
-// 16-column groups per row
-template <int NH>
-struct Geo {
-    static_assert(NH == 128 || NH == 256 || NH == 512, "two-pass path: nx must be 256, 512 or 1024");
-    static constexpr int pitch = NH + kW, groups = NH / kW;
-};
-
-// Buffer addressing: one 32-bit lane offset + a scalar offset per access, so that the 64 accesses of a register tile
-// share ONE address register instead of 64 pointer pairs.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long long bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-// Streams and the 256 MB Infinity Cache.  AUX = the cache-policy bits of a buffer access (gfx942 / gfx950: 1 = sc0, 2 = nt,
-// 16 = sc1).  An iteration moves ~3.5 GB through a memory-side cache of 256 MB; what profits from it is the SPECTRUM, written
-// by one kernel and read back by the next (268 MB at 512 x 512 x 256).  Everything touched once per iteration -- the OTFs, the
-// measured image, the estimate -- only pushes spectrum lines out, so in the STREAM instantiations of the register kernels those
-// accesses carry the non-temporal hint: 512 x 512 x 256 on one box 1 240 it/s without, 1 295 with the OTF and image / estimate
-// loads marked, 1 361 with the estimate's store marked too; marking the SPECTRUM instead loses 5-6 %
-// (profiles/r05/nontemporal_streams.txt).  Boxes whose whole working set fits the cache (volumes of a few ten MB) lose 4-7 %
-// with the hint -- their OTFs and images would have stayed -- so the host picks the instantiation by volume size
-// (ConvPlan::stream_, MIL_FX_STREAM=0 / 1 forces it).
-template <bool STREAM>
-struct Aux {
-    static constexpr int ld_spec = 0, st_spec = 0;
-    static constexpr int ld_otf = STREAM ? 2 : 0, ld_real = STREAM ? 2 : 0, st_real = STREAM ? 2 : 0;
-};
-template <int AUX = 0>
-__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, AUX);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-template <int AUX = 0>
-__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 x) {
-    u32x2 v;
-    v.x = __float_as_uint(x.x);
-    v.y = __float_as_uint(x.y);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, AUX);
-}
-// Twiddles of the in-register stages: their index is uniform over a wave, and from constant memory that is a scalar
-// load into SGPRs (through a kernel argument the compiler cannot prove the table read-only and fetches every twiddle
-// into a vector register: +40 registers, spills).  Filled by ConvPlan::init_two_pass on the current device.
-// One table per y extent: engines of different boxes may live on the same device (host threads), and each writes only
-// its own table -- with the same values every time.
-struct TwYTables {
-    float2 w128[128], w256[256], w512[512], w1024[1024];
-};
-__constant__ TwYTables c_tw_y;
-__constant__ float2 c_tw_z[kNZ];
-template <int NY>
-__device__ __forceinline__ const float2 *tw_y_const() {
-    static_assert(NY == 128 || NY == 256 || NY == 512 || NY == 1024, "two-pass path: y extent");
-    if constexpr (NY == 128) return c_tw_y.w128;
-    else if constexpr (NY == 256) return c_tw_y.w256;
-    else if constexpr (NY == 512) return c_tw_y.w512;
-    else return c_tw_y.w1024;
-}
-
-// The y tail: the in-place transform of length T = NY / 64 over T adjacent rows.  For T <= 8 it is one radix-T stage
-// (natural order); for T = 16 the classic schedule is radix 8 then radix 2, which leaves frequency f = k1 + 8 k2 at row
-// 2 k1 + k2.  tail_forward: rows in natural order -> frequencies at their classic positions; tail_inverse: the reverse.
-template <int T>
-__device__ __forceinline__ int tail_pos(int f) {
-    return T == 16 ? 2 * (f & 7) + (f >> 3) : f;
-}
-template <int T>
-__device__ __forceinline__ void tail_forward(float2 *p, int stride) {
-    float2 t[T];
-#pragma unroll
-    for (int k = 0; k < T; ++k) t[k] = p[k * stride];
-    dft_small<T, -1>(t);
-#pragma unroll
-    for (int k = 0; k < T; ++k) p[tail_pos<T>(k) * stride] = t[k];
-}
-template <int T>
-__device__ __forceinline__ void tail_inverse(float2 *p, int stride) {
-    float2 t[T];
-#pragma unroll
-    for (int k = 0; k < T; ++k) t[k] = p[tail_pos<T>(k) * stride];
-    dft_small<T, +1>(t);
-#pragma unroll
-    for (int k = 0; k < T; ++k) p[k * stride] = t[k];
-}
-
-
-// ---------------------------------------------------------------------------
-// partial y passes (classic column tiles): head = the first two (radix-8) stages, tail = the sub-transforms of length T = N / 64
-// ---------------------------------------------------------------------------
-struct PartArgs {
-    float2 *S;
-    const float2 *tw;
-    float2 *col0;  // forward tail: copy of the completed packed column, as the classic forward y pass writes it
-    long long row_stride, outer_stride;
-    int groups;
-};
-
-template <int N, int NT, int PART>
-__global__ __launch_bounds__(NT) void col_part_kernel(PartArgs a) {
-    constexpr int T = N / 64;
-    __shared__ float2 tile[N * kWP];
-    __shared__ float2 tw[N];
-    const int g = blockIdx.x % a.groups;
-    const long long outer = blockIdx.x / a.groups;
-    float2 *base = a.S + outer * a.outer_stride + (long long)g * kW;
-    for (int k = threadIdx.x; k < N; k += NT) tw[k] = a.tw[k];
-    tile_load<N, NT>(tile, base, a.row_stride);
-    lds_barrier();
-    if constexpr (PART == 0) fft_dif<N, N, -1, kW, NT, kWP, T>(tile, tw);
-    else if constexpr (PART == 1) fft_dit<N, N, +1, kW, NT, T>(tile, tw);
-    else if constexpr (PART == 2) fft_dif<N, T, -1, kW, NT, kWP>(tile, tw);
-    else fft_dit<N, T, +1, kW, NT>(tile, tw);
-    tile_store<N, NT>(tile, base, a.row_stride);
-    if constexpr (PART == 2) {
-        if (g == 0 && a.col0)
-            for (int k = threadIdx.x; k < N; k += NT) a.col0[outer * N + k] = tile[k * kWP];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// yz_conv: y stage(8), z, OTF, z^-1, y stage(8)^-1 on 8 rows x 16 columns x 256 z held in registers
-// ---------------------------------------------------------------------------
-struct YzArgs {
-    float2 *S;
-    const float2 *otf;    // classic tiling [row][g][kz][16]
-    const float2 *otf_q;  // [row][kz]
-    const unsigned short *neg_y, *neg_z;
-    const unsigned short *pairs;  // [pair][2]: row blocks holding ky and -ky (packed column)
-    int pair_blocks;              // the first blocks do the packed column, one pair of row blocks each (short: they
-                                  // start first so that the long tiles fill in behind them instead of waiting at the end)
-    unsigned long long *stamps;   // timing experiments: 8 wall-clock stamps (100 MHz) per workgroup, or null
-};
-
-#ifdef MIL_FX_STAMPS  // timing experiments: wall-clock stamps at the phase boundaries of one workgroup (tools/twopass_stamps.py)
-#define MIL_STAMP(i)                                                                   \
-    do {                                                                               \
-        if (a.stamps && threadIdx.x == 0) a.stamps[(blockIdx.x % 2048) * 16 + (i)] = wall_clock64(); \
-    } while (0)
-#else
-#define MIL_STAMP(i)
-#endif
-
-constexpr int kYzThreads = 512;
-constexpr int kQuarter = 16;             // registers exchanged at a time (a quarter of the thread's 64)
-constexpr int kPark = 23;                // values of the waiting quarters parked in the rest of the 160 KB
-
-// value of the neighbouring lane (lane ^ 1)
-__device__ __forceinline__ float2 swap_pair(float2 a) {
-    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
-    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(a.y), 0xB1, 0xF, 0xF, false);
-    return make_float2(__int_as_float(x), __int_as_float(y));
-}
-
-// ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
-// One workgroup per pair of row blocks, 2 x T rows x NZ z of column 0 in LDS as tile[z][17].  `tw`: w_NZ^k, any address
-// space the 512 threads may index freely.
-template <int NY, int NZ, int NH, int NT = 512>
-__device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *tile, const float2 *tw, int pair) {
-    constexpr int T = NY / 64, C = 2 * T;  // rows per block, columns of the tile in use
-    constexpr int PW = C > kW ? C : kW, PWP = PW + 1;  // tile[z][PW + 1]
-    constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
-    const int tid = threadIdx.x;
-    const int blk[2] = {a.pairs[2 * pair], a.pairs[2 * pair + 1]};
-    for (int i = tid; i < NZ * C; i += NT) {
-        const int c = i % C, z = i / C;
-        tile[z * PWP + c] = a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch];
-    }
-    if (C < PW)  // the z stages below run over all PW columns of the tile: keep the unused ones finite
-        for (int i = tid; i < NZ * (PW - C); i += NT) tile[(i / (PW - C)) * PWP + C + i % (PW - C)] = make_float2(0.f, 0.f);
-    lds_barrier();
-    for (int i = tid; i < NZ * 2; i += NT) tail_forward<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
-    lds_barrier();
-    fft_dif<NZ, NZ, -1, PW, NT, PWP>(tile, tw);
-    constexpr int PER = (NZ * C + NT - 1) / NT;
-    float2 r[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = i * NT + tid, c = e % C, p = e / C;
-        if (e < NZ * C) {
-            const int row = T * blk[c / T] + (c % T);
-            const int prow = a.neg_y[row];
-            const int pc = ((prow / T) == blk[0] ? 0 : T) + (prow % T);
-            const float2 gk = tile[p * PWP + c], gp = tile[a.neg_z[p] * PWP + pc];
-            const float2 pv = a.otf[(((long long)row * kGroups) * NZ + p) * kW];
-            const float2 qv = a.otf_q[(long long)row * NZ + p];
-            r[i] = c_add(c_mul(gk, pv), c_mul(qv, make_float2(gp.x, -gp.y)));
-        }
-    }
-    lds_barrier();
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int e = i * NT + tid;
-        if (e < NZ * C) tile[(e / C) * PWP + (e % C)] = r[i];
-    }
-    lds_barrier();
-    fft_dit<NZ, NZ, +1, PW, NT>(tile, tw);
-    for (int i = tid; i < NZ * 2; i += NT) tail_inverse<T>(tile + (i >> 1) * PWP + T * (i & 1), 1);
-    lds_barrier();
-    const int ncol = (blk[0] == blk[1]) ? T : C;
-    for (int i = tid; i < NZ * C; i += NT) {
-        const int c = i % C, z = i / C;
-        if (c < ncol) a.S[((long long)z * NY + T * blk[c / T] + (c % T)) * kPitch] = tile[z * PWP + c];
-    }
-}
-
-// COLS = 16: 512 threads, one workgroup per CU (the 256 KB tile).  COLS = 8: 256 threads and half the tile, TWO workgroups
-// per CU whose load / exchange / store phases overlap; the two halves of every 128-byte row segment go to workgroups t and
-// t + 8 -- the same XCD, a few dispatches apart -- so that HBM still sees whole lines (unpaired, the 64-byte segments cost
-// what the overlap gains: round 2).
-template <int NH, int COLS, bool STREAM>
-__global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
-    static_assert(COLS == 16 || COLS == 8, "yz_conv_kernel: 16- or 8-column tiles");
-    constexpr int THREADS = 32 * COLS;           // COLS columns x 8 rows x 4 z-residues
-    constexpr int kXchg = 4 * 8 * COLS + COLS;   // float2 between consecutive exchanged registers: 4 z-residues x 8 rows x COLS
-                                                 // columns (+ COLS: the register slots a wave reads at once fall on different bank halves)
-    constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
-    constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8, kOtfBytes = (long long)NH * kNY * kNZ * 8;
-    // exchange buffer of one quarter (66 KB) + parking space (92 KB): registers are the scarce resource of this kernel,
-    // every spilled one is HBM traffic
-    __shared__ float2 lds[kQuarter * kXchg + kPark * THREADS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float2 *twz = c_tw_z;  // in-register stages; the packed-column path below uses the same table through LDS-style code
-    if ((int)blockIdx.x >= a.pair_blocks) {
-        const int tile_id = blockIdx.x - a.pair_blocks;
-        int g = tile_id % (NH / COLS), b = tile_id / (NH / COLS);  // g: COLS-column group
-        if constexpr (COLS == 8) {  // XCD pairing of the two halves of a 16-column group (see yz_lds_kernel)
-            const int tt = tile_id % 16, q = tile_id / 16;
-            g = 2 * ((q % (NH / 128)) * 8 + (tt % 8)) + tt / 8;
-            b = q / (NH / 128);
-        }
-        const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // 16-column group of the OTF tiling, offset inside it
-        // ownership 1: all z = za + 4m (m = j2 + 8 j1) of one (row j, column)
-        const int col = lane & (COLS - 1), za = wave & 3, j = (lane / COLS) + (64 / COLS) * (wave >> 2);
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes), ro = make_rsrc(a.otf, kOtfBytes);
-        const unsigned voff = (unsigned)(j * kPitch + col) * 8u;
-        const unsigned soff0 = (unsigned)((za * kNY + 8 * b) * kPitch + g * COLS) * 8u;  // + m * zstep
-        constexpr unsigned zstep = 4u * kNY * kPitch * 8u;
-        // ownership 2 (per quarter q: ka = 2q, 2q + 1): a PAIR of lanes shares the 8 rows x 4 z-residues of one (register
-        // slot kk = kb + 8 (ka - 2q), column); lane sp of the pair holds rows sp, sp + 2, sp + 4, sp + 6 going in and the
-        // row frequencies 4 sp .. 4 sp + 3 at the OTF product (the radix-8 row butterfly split over the pair)
-        const int sp = tid & 1, scol = (tid >> 1) & (COLS - 1), skk = tid / (2 * COLS);
-        const unsigned ooff0 = (unsigned)((((8 * b) * kGroups + g16) * kNZ) * kW) * 8u;  // wave-uniform part (scalar offset)
-        const unsigned ovoff = (unsigned)((4 * sp * kGroups * kNZ + 4 * (skk & 7) + 32 * (skk >> 3)) * kW + c16 + scol) * 8u;  // row 4 sp, position 4 kb + 32 (ka - 2q)
-        float2 v[64], o[2][16];
-        auto load_otf = [&](int q) {  // position kc + 4 kb + 32 ka of row frequency 4 sp + k
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc)
-                    o[q & 1][kc * 4 + k] = buf_load2<Aux<STREAM>::ld_otf>(ro, ovoff, ooff0 + (unsigned)((k * kGroups * kNZ + 64 * q + kc) * kW) * 8u);
-        };
-        MIL_STAMP(0);
-#pragma unroll
-        for (int m = 0; m < 64; ++m) v[m] = buf_load2<Aux<STREAM>::ld_spec>(rs, voff, soff0 + m * zstep);
-        load_otf(0);
-        load_otf(1);
-        // ---- z forward, stages L = 256 (over j1) and L = 32 (over j2), in registers
-#pragma unroll
-        for (int j2 = 0; j2 < 8; ++j2) {
-            float2 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
-            dft8<-1>(t);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twz[(za + 4 * j2) * k]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
-        }
-#pragma unroll
-        for (int ka = 0; ka < 8; ++ka) {
-            float2 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * ka];
-            dft8<-1>(t);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twz[za * k * 8]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k + 8 * ka] = t[k];
-        }
-        MIL_STAMP(1);
-        float2 *mine = lds + za * (8 * COLS) + j * COLS + col;         // + kk * kXchg
-        float2 *slot = lds + skk * kXchg + sp * COLS + scol;            // + a * 8 * COLS + i * 2 * COLS   (row sp + 2 i)
-        float2 *park = lds + kQuarter * kXchg + tid;                   // + i * THREADS, this thread's own slots
-        // Parking plan (values by register index): v[32..54] wait in LDS from the start; when quarter 2 / 3 picks its inputs
-        // up, the results of quarter 0 / 1 take the freed places; everything comes back after the last quarter.
-#pragma unroll
-        for (int i = 0; i < kPark; ++i) park[i * THREADS] = v[32 + i];
-        constexpr float h8 = 0.70710678118654752440f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q == 2) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    v[32 + i] = park[i * THREADS];
-                    park[i * THREADS] = v[i];  // results of quarter 0
-                }
-            }
-            if (q == 3) {
-#pragma unroll
-                for (int i = 16; i < kPark; ++i) {
-                    v[32 + i] = park[i * THREADS];
-                    park[i * THREADS] = v[i];  // 7 results of quarter 1
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) mine[kk * kXchg] = v[16 * q + kk];
-            if (q == 0) MIL_STAMP(8);
-            lds_barrier();
-            if (q == 0) MIL_STAMP(9);
-            float2 u[16];  // [a][i]: z-residue a, row sp + 2 i
-#pragma unroll
-            for (int e = 0; e < 16; ++e) u[e] = slot[(e >> 2) * (8 * COLS) + (e & 3) * (2 * COLS)];
-            // y stage of length 8 over the rows, split over the lane pair (decimation in time): each lane transforms its four
-            // rows, the odd lane applies w8^k, then  row k = even + odd,  row k + 4 = even - odd
-#pragma unroll
-            for (int za2 = 0; za2 < 4; ++za2) {
-                float2 *w = u + 4 * za2;
-                dft4<-1>(w[0], w[1], w[2], w[3]);
-                if (sp) {
-                    w[1] = c_add(w[1], rot90<-1>(w[1])) * make_float2(h8, h8);
-                    w[2] = rot90<-1>(w[2]);
-                    w[3] = c_sub(rot90<-1>(w[3]), w[3]) * make_float2(h8, h8);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float2 oth = swap_pair(w[k]);
-                    w[k] = sp ? c_sub(oth, w[k]) : c_add(w[k], oth);
-                }
-            }
-            // z stage of length 4 over the residues
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dft4<-1>(u[k], u[4 + k], u[8 + k], u[12 + k]);
-            if (q == 0) MIL_STAMP(10);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) u[e] = c_mul(u[e], o[q & 1][e]);
-            if (q == 0) MIL_STAMP(11);
-            if (q + 2 < 4) load_otf(q + 2);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dft4<+1>(u[k], u[4 + k], u[8 + k], u[12 + k]);
-            // y stage back (decimation in frequency): s = x_r + x_(r+4) on the even lane, d = (x_r - x_(r+4)) w8^-r on the odd
-            // one, then each lane transforms its four: even lane -> rows 0, 2, 4, 6, odd lane -> rows 1, 3, 5, 7
-#pragma unroll
-            for (int za2 = 0; za2 < 4; ++za2) {
-                float2 *w = u + 4 * za2;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float2 oth = swap_pair(w[k]);
-                    w[k] = sp ? c_sub(oth, w[k]) : c_add(w[k], oth);
-                }
-                if (sp) {
-                    w[1] = c_add(w[1], rot90<+1>(w[1])) * make_float2(h8, h8);
-                    w[2] = rot90<+1>(w[2]);
-                    w[3] = c_sub(rot90<+1>(w[3]), w[3]) * make_float2(h8, h8);
-                }
-                dft4<+1>(w[0], w[1], w[2], w[3]);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) slot[(e >> 2) * (8 * COLS) + (e & 3) * (2 * COLS)] = u[e];
-            if (q == 0) MIL_STAMP(12);
-            lds_barrier();
-            if (q == 0) MIL_STAMP(13);
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) v[16 * q + kk] = mine[kk * kXchg];
-            if (q < 2) MIL_STAMP(2 + q);
-        }
-#pragma unroll
-        for (int i = 0; i < kPark; ++i) v[i] = park[i * THREADS];
-        // ---- z inverse, stages L = 32 and L = 256
-#pragma unroll
-        for (int ka = 0; ka < 8; ++ka) {
-            float2 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * ka];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twz[za * k * 8]);
-            dft8<+1>(t);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k + 8 * ka] = t[k];
-                }
-#pragma unroll
-        for (int j2 = 0; j2 < 8; ++j2) {
-            float2 t[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twz[(za + 4 * j2) * k]);
-            dft8<+1>(t);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
-                }
-        MIL_STAMP(4);
-        if (g != 0 || col != 0) {  // the packed column belongs to the pair blocks below
-#pragma unroll
-            for (int m = 0; m < 64; ++m) buf_store2<Aux<STREAM>::st_spec>(rs, voff, soff0 + m * zstep, v[m]);
-        }
-        MIL_STAMP(5);
-#ifdef MIL_FX_STAMPS
-        if (a.stamps) {
-            __builtin_amdgcn_s_waitcnt(0);
-            MIL_STAMP(6);
-        }
-#endif
-        return;
-    }
-    packed_column_block<kNY, kNZ, NH, THREADS>(a, lds, twz, (int)blockIdx.x);
-}
-
-// ---------------------------------------------------------------------------
-// yz_conv where the tile fits the LDS: T rows (T = NY / 64, the y tail) x COLS columns x NZ z <= 16384 complex = 128 KB
-// + padding -- COLS = 16 (128-byte row segments) for T x NZ <= 1024, 8 or 4 columns for the taller boxes -- so the sequence
-//   y tail(T) . z . OTF . z^-1 . y tail(T)^-1
-// runs on tile[z][T rows x 16 columns] with the classic LDS stage code, T * 16 "columns" per z position.  One trip of the
-// spectrum through HBM (3 C'') where the classic kernels make three (y tail | z-conv | y tail^-1: 7 C'').
-// ---------------------------------------------------------------------------
-template <int NY, int NZ, int NH, int COLS, bool XCDPAIR = false>
-__global__ __launch_bounds__(kYzThreads) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
-    constexpr int T = NY / 64;
-    // COLS columns per tile: 16 (128-byte row segments) wherever T x NZ x 16 complex fit the LDS, else 8 or 4
-    static_assert(T * NZ * COLS <= 16384 && (COLS == 16 || COLS == 8 || COLS == 4), "yz_lds_kernel: tile does not fit the LDS");
-    constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
-    constexpr int W = T * COLS, WP = W + 1;  // row r, column c of the block sit at "column" r * COLS + c
-    constexpr int QR = COLS / 2;             // float4 pieces per row segment
-    constexpr int PWP = (2 * T > kW ? 2 * T : kW) + 1;  // packed_column_block's tile
-    __shared__ float2 tile[NZ * WP > NZ * PWP ? NZ * WP : NZ * PWP];
-    __shared__ float2 tw[NZ];
-    const int tid = threadIdx.x;
-    for (int k = tid; k < NZ; k += kYzThreads) tw[k] = tw_z[k];
-    if ((int)blockIdx.x < a.pair_blocks) {
-        lds_barrier();
-        packed_column_block<NY, NZ, NH>(a, tile, tw, (int)blockIdx.x);
-        return;
-    }
-    constexpr int GROUPS = NH / COLS;
-    const int tile_id = blockIdx.x - a.pair_blocks;
-    int g = tile_id % GROUPS, b = tile_id / GROUPS;
-    if constexpr (XCDPAIR) {
-        // Narrow tiles (8 / 4 columns): the 2 / 4 pieces of a 128-byte row segment go to workgroups t, t + 8 (, t + 16,
-        // t + 24), i.e. to the SAME XCD (workgroups are dealt round-robin over the 8 XCDs) a few dispatches apart: the first
-        // one brings the line into that XCD's L2, the others find it there -- HBM sees whole lines again.
-        static_assert(!XCDPAIR || COLS < kW, "pairing is for narrow tiles");
-        constexpr int SUB = kW / COLS;
-        const int tt = tile_id % (8 * SUB), q = tile_id / (8 * SUB);
-        const int g16x = (q % (NH / 128)) * 8 + (tt % 8);  // 16-column group
-        g = SUB * g16x + tt / 8;
-        b = q / (NH / 128);
-    }
-    const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // the 16-column group of the OTF tiling, offset inside it
-    float2 *base = a.S + (long long)(T * b) * kPitch + g * COLS;
-    constexpr long long zstride = (long long)NY * kPitch;
-    // ---- load: NZ x T row segments
-    constexpr int TOTAL = NZ * T * QR;  // float4 pieces
-#pragma unroll 1
-    for (int it0 = 0; it0 < TOTAL; it0 += kYzThreads * kBatch) {
-        float4 v[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kYzThreads + tid;
-            const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
-            if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(base + z * zstride + (long long)row * kPitch + 2 * q);
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kYzThreads + tid;
-            const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
-            if (idx < TOTAL) {
-                float2 *p = tile + z * WP + row * COLS + 2 * q;
-                p[0] = make_float2(v[j].x, v[j].y);
-                p[1] = make_float2(v[j].z, v[j].w);
-            }
-        }
-    }
-    lds_barrier();
-    // ---- y tail: the transform of length T over the rows of every (z, column)
-    for (int i = tid; i < NZ * COLS; i += kYzThreads) tail_forward<T>(tile + (i / COLS) * WP + (i % COLS), COLS);
-    lds_barrier();
-    fft_dif<NZ, NZ, -1, W, kYzThreads, WP>(tile, tw);
-    // ---- OTF product: the classic tiling [row][16-column group][kz][16]
-    {
-        constexpr int PIECES = T * NZ * QR;  // float4 pieces
-#pragma unroll 1
-        for (int it0 = 0; it0 < PIECES; it0 += kYzThreads * kBatch) {
-            float4 v[kBatch];
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const int idx = it0 + j * kYzThreads + tid;
-                const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
-                if (idx < PIECES)
-                    // no stream hint here: the boxes of this kernel are small enough for their OTFs to survive in the Infinity
-                    // Cache from one iteration to the next (hinted: -4 % at 64 MB volumes, profiles/r05/nontemporal_streams.txt)
-                    v[j] = *reinterpret_cast<const float4 *>(a.otf + ((((long long)(T * b + row) * kGroups + g16) * NZ + kz) * kW) + c16 + 2 * q);
-            }
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const int idx = it0 + j * kYzThreads + tid;
-                const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
-                if (idx < PIECES) {
-                    float2 *p = tile + kz * WP + row * COLS + 2 * q;
-                    p[0] = c_mul(p[0], make_float2(v[j].x, v[j].y));
-                    p[1] = c_mul(p[1], make_float2(v[j].z, v[j].w));
-                }
-            }
-        }
-    }
-    lds_barrier();
-    fft_dit<NZ, NZ, +1, W, kYzThreads>(tile, tw);
-    for (int i = tid; i < NZ * COLS; i += kYzThreads) tail_inverse<T>(tile + (i / COLS) * WP + (i % COLS), COLS);
-    lds_barrier();
-    // ---- store; the packed column (group 0, column 0) belongs to the pair blocks
-#pragma unroll 4
-    for (int idx = tid; idx < TOTAL; idx += kYzThreads) {
-        const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
-        const float2 *p = tile + z * WP + row * COLS + 2 * q;
-        float2 *dst = base + z * zstride + (long long)row * kPitch + 2 * q;
-        if (g == 0 && q == 0) dst[1] = p[1];
-        else *reinterpret_cast<float4 *>(dst) = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// xy pass: the 64 rows y = n2 + T m (T = NY / 64) of one z plane in registers (thread = column); y head^-1, then per 16 rows
-// x^-1 . op . x through LDS (the classic x kernel's tile), then y head
-// ---------------------------------------------------------------------------
-struct XyArgs {
-    float2 *S;
-    float *E;        // estimate (in / out), update modes
-    const float *M;  // measured image, ratio mode
-    const float2 *tw_x;
-    float eps;
-    long long spec_bytes, real_bytes;  // extents of S and of the real volumes (buffer descriptors)
-    unsigned long long *stamps;  // timing experiments: 8 wall-clock stamps (100 MHz) per workgroup, or null
-};
-
-
-// The x transform of length NH runs as NH = 16 x M: element k = a + 16 b (a < 16, b < M) of the half-length sequence sits at
-// position a * M + pos_M(b), where pos_M is the in-place order of the length-M sub-transforms (one radix-8 / radix-16 LDS
-// stage for M = 8 / 16: the identity; radix 8 then radix 4 for M = 32: 4 (b % 8) + b / 8).
-template <int M>
-__device__ __forceinline__ int xy_pos_m(int b) {
-    return M == 32 ? 4 * (b & 7) + (b >> 3) : b;
-}
-
-// the LDS stage(s) of length M = NH / 16 of the x transform, on the skewed 16-row tile
-template <int NH, bool DIT, int SIGN>
-__device__ __forceinline__ void xy_stage_m(float2 *tile, const float2 *tw) {
-    constexpr int M = NH / 16, RB = 16;
-    if constexpr (M == 32) {  // radix 8 . radix 4 (the schedule of fft_dif / fft_dit for length 32)
-        if constexpr (DIT) {
-            fft_stage<NH, 4, 4, true, SIGN, RB, NH, RB + 1, M>(tile, tw);
-            lds_barrier();
-            fft_stage<NH, 8, 32, true, SIGN, RB, NH, RB + 1, M>(tile, tw);
-        } else {
-            fft_stage<NH, 8, 32, false, SIGN, RB, NH, RB + 1, M>(tile, tw);
-            lds_barrier();
-            fft_stage<NH, 4, 4, false, SIGN, RB, NH, RB + 1, M>(tile, tw);
-        }
-    } else {
-        fft_stage<NH, M, M, DIT, SIGN, RB, NH, RB + 1, M>(tile, tw);
-    }
-}
-
-// Occupancy.  The 64 rows x NH columns of a workgroup live in registers (128 per thread), which left room for two waves per
-// SIMD; two waves spent 31 % of the time both waiting (loads, barriers, LDS round trips).  For NH <= 256 the kernel is built
-// for THREE (<= 168 registers, three / six workgroups per CU):
-//   * PARK = 8 of the 64 values wait in LDS (thread-private slots, 16 KB at NH = 256 -- all that three workgroups leave);
-//   * the fused radix-16 stage runs as radix 2 (across lanes l and l + 32) x radix 8 (in the lane): 8 + 8 instead of
-//     16 + 16 complex temporaries;
-//   * addresses and twiddles of the trip loop are recomputed per trip (hoisted, they were what got spilled).
-// NH = 512 (eight waves per workgroup, 74 KB of tile) stays at two waves per SIMD without parking.
-template <int NH>
-struct XyCfg {
-    static constexpr int occ = NH == 512 ? 2 : 3;
-    static constexpr int park = NH == 512 ? 0 : 8;
-};
-
-// lanes l and l + 32 exchange (v_permlane32_swap):  a' = (a of the lower lanes | b of the LOWER lanes),
-// b' = (a of the UPPER lanes | b of the upper lanes)
-__device__ __forceinline__ void swap32(float2 &a, float2 &b) {
-    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
-    const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
-    a = make_float2(__uint_as_float(x[0]), __uint_as_float(y[0]));
-    b = make_float2(__uint_as_float(x[1]), __uint_as_float(y[1]));
-}
-
-// m / t: reciprocal, two Newton steps, v_div_fixup for the special cases -- the IEEE sequence without its range scaling
-// (6 instead of 10 instructions; 32 divisions per thread and trip were 13 % of the ratio kernel's arithmetic).  Within one
-// unit in the last place of the correctly rounded quotient for normal |t| below 2^126; outside that range (zero and
-// denormal denominators, where the reciprocal overflows and the Newton step would turn inf into NaN, or huge ones, whose
-// reciprocal flushes to zero) the lanes concerned take the IEEE division -- the quotient of the reference's unguarded
-// div3Dkernel, +-inf at t = 0 included.  Two compares per division; the branch is never taken on real data (T is N times
-// a positive estimate).
-__device__ __forceinline__ float xy_div(float m, float t) {
-    float r = __builtin_amdgcn_rcpf(t);
-    r = __builtin_fmaf(__builtin_fmaf(-t, r, 1.0f), r, r);
-    float q = m * r;
-    q = __builtin_fmaf(__builtin_fmaf(-t, q, m), r, q);
-    q = __builtin_amdgcn_div_fixupf(q, t, m);
-    constexpr int kNormal = 0x008 | 0x100;  // v_cmp_class: -normal | +normal
-    if (__builtin_expect(!(__builtin_amdgcn_classf(t, kNormal) && __builtin_fabsf(t) < 0x1p126f), 0)) q = m / t;
-    return q;
-}
-
-template <int MODE, int NY, int NH, bool STREAM>
-__global__ __launch_bounds__(NH, XyCfg<NH>::occ) void xy_kernel(XyArgs a) {
-    constexpr int T = NY / 64;  // length of the y tail = distance between the rows of this workgroup
-    constexpr int M = NH / 16;  // length of the LDS stage of the x transform
-    constexpr int kPitch = Geo<NH>::pitch;
-    constexpr int RB = 16, WP = RB + 1, NX = 2 * NH;  // 16 rows per trip through LDS: tile[position][row]
-    constexpr int PARK = XyCfg<NH>::park, NV = 64 - PARK;
-    // position p of the half-length sequence, row r: tile[p * WP + p / M + r] -- the skew keeps the fold / split, which
-    // step through the positions M at a time, from hammering two banks (54 % of the LDS cycles were conflicts without it)
-    __shared__ float2 tile[NH * WP + 16];
-    __shared__ float2 tw[NH];  // w_NH^k = w_NX^(2k): the packed complex transform
-    __shared__ float2 parked[PARK > 0 ? PARK * NH : 1];
-    const int tid = threadIdx.x;
-    float2 *park = parked + tid;  // + i * NH: this thread's own slots
-    const int n2 = blockIdx.x % T, z = blockIdx.x / T;
-    const float2 *twy = tw_y_const<NY>();
-    tw[tid] = a.tw_x[2 * tid];
-    // This thread's spectrum column is X[kc] (even columns) or X[NH - kc] (odd), kc = tid / 2; columns 0 / 1 are the packed
-    // (X[0], X[NH]) and X[NH/2].  The element e = a + 16 b of the half-length sequence it folds to / splits from sits at
-    // position M * slot(a) + pos_M(b): block slot(a) = 2 (a mod 8) + a / 8 of the 16 blocks of length M (the order the
-    // radix-2 x radix-8 fused stage wants its sub-transforms in).
-    const int kc = tid >> 1;
-    const bool odd = tid & 1;
-    const int ez = tid == 1 ? NH / 2 : (odd ? NH - kc : kc);
-    const int pz = M * (2 * (ez & 7) + ((ez >> 3) & 1)) + xy_pos_m<M>(ez >> 4);
-    const int pzs = pz * WP + pz / M;  // its place in the skewed tile
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, a.spec_bytes);
-    const __amdgpu_buffer_rsrc_t rr = make_rsrc(MODE == kXRatio ? a.M : a.E, a.real_bytes);
-    const unsigned voff = (unsigned)tid * 8u;
-    const unsigned soff0 = (unsigned)((z * NY + n2) * kPitch) * 8u;  // + m * rstep
-    constexpr unsigned rstep = (unsigned)T * kPitch * 8u;
-    // Fused stage: lanes l and l + 32 (h = 0, 1) share the butterflies i = sbi of row srow (+ 8 in the second pass).  Lane h
-    // works on the positions 2 M c + M h + sbi (c < 8: block c, half h), which the radix-8 stage turns into the real-space
-    // elements n = si + 2 M r (x = 2 n, 2 n + 1): a wave's M / E access is 256 contiguous bytes of each of its rows.
-    // Tile row r is volume row y = n2 + T r + 16 T grp.
-    const int slow = tid & 31, sh = (tid >> 5) & 1;
-    const int sbi = slow % M, srow = slow / M + (32 / M) * (tid >> 6);
-    const int si = sbi + M * sh;
-    float2 *sp = tile + si * WP + sh + srow;  // + c * SCS (block c) + 8 (second pass)
-    constexpr int SCS = 2 * M * WP + 2;
-    const unsigned svoff = (unsigned)(srow * T * NX + 2 * si) * 4u;
-    const unsigned rsoff0 = (unsigned)((z * NY + n2) * NX) * 4u;  // + grp * 16 T rows, + pass * 8 T rows, + 4 M r floats
-    constexpr unsigned rgrp = 16u * T * NX * 4u, spass = 8u * T * NX * 4u, srj = 4u * M * 4u;
-    float2 v[64];
-    float2 pre[16];  // M / E of the trip's two passes
-    MIL_STAMP(0);
-    // Hermitian fold / split.  With A = own + oth, B = own - oth (oth = the pair lane's value) both lanes of a pair evaluate
-    // the SAME expressions -- no per-lane selects (they were a fifth of the kernel's arithmetic):
-    //   fold   Z' = (A.x - c1 A.y + c2 B.x,      B.y + c1 B.x + c2 A.y)        c1 = +/- w.x (even / odd lane), c2 = w.y
-    //   split  X  = (A.x / 2 + h1 A.y + h2 B.x,  B.y / 2 - h1 B.x + h2 A.y)    h1 = c1 / 2, h2 = c2 / 2,  w = w_NX^kc
-    const float2 wf = a.tw_x[kc];
-    const float fc1 = odd ? -wf.x : wf.x, fc2 = wf.y, fh1 = 0.5f * fc1, fh2 = 0.5f * fc2;
-#pragma unroll
-    for (int m = 0; m < 64; ++m) v[m] = buf_load2<Aux<STREAM>::ld_spec>(rs, voff, soff0 + m * rstep);
-    // ---- y inverse head: DIT stages L = NY / 8 (over j2, m = j2 + 8 j1; element i = n2 of its sub-transform) and L = NY
-    // (over j1; element i = n2 + T j2)
-#pragma unroll
-    for (int j1 = 0; j1 < 8; ++j1) {
-        float2 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * j1];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twy[n2 * k * 8]);
-        dft8<+1>(t);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k + 8 * j1] = t[k];
-    }
-#pragma unroll
-    for (int j2 = 0; j2 < 8; ++j2) {
-        float2 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], twy[(n2 + T * j2) * k]);
-        dft8<+1>(t);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
-    }
-    MIL_STAMP(1);
-    // The rows form a queue: the trip works on its first 16, the results join at the end; its last PARK places are in LDS.
-#pragma unroll
-    for (int i = 0; i < PARK; ++i) park[i * NH] = v[NV + i];
-    lds_barrier();  // tw
-    // ---- x^-1 . op . x, sixteen rows per trip (rows m = r + 16 grp).  A real loop: the rows in flight always sit in
-    // v[0..15] and the queue moves up by one group per trip.  (Unrolled, the compiler parks half of the tile in scratch.)
-#pragma unroll 1
-    for (int grp = 0; grp < 64 / RB; ++grp) {
-        const unsigned rsoff = rsoff0 + grp * rgrp;
-        // Hermitian fold, straight from the registers: the lane pair (2k, 2k + 1) holds (X[k], X[NH-k]); each lane forms
-        // its own element of the packed half-length sequence Z' and drops it at that element's position.
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const float2 own = v[r], oth = swap_pair(own);
-            const float2 A = c_add(own, oth), B = c_sub(own, oth);
-            tile[pzs + r] = make_float2(A.x - fc1 * A.y + fc2 * B.x, B.y + fc1 * B.x + fc2 * A.y);
-        }
-        if (tid < 2) {  // lanes 0 / 1 hold the packed (X[0], X[NH]) and X[NH/2]: their elements are written again
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const float2 own = v[r];
-                tile[pzs + r] = tid == 0 ? make_float2(own.x + own.y, own.x - own.y)  // Z'[0]
-                                         : make_float2(2.f * own.x, -2.f * own.y);     // Z'[NH/2] = 2 conj(X[NH/2])
-            }
-        }
-        // M / E of the first pass of the fused stage: in flight during the LDS stage (v[0..15] are free now)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) pre[r] = buf_load2<Aux<STREAM>::ld_real>(rr, svoff, rsoff + r * srj);
-        if (grp == 0) MIL_STAMP(8);
-        lds_barrier();
-        if (grp == 0) MIL_STAMP(9);
-        xy_stage_m<NH, true, +1>(tile, tw);  // DIT stage(s) of length M
-        lds_barrier();
-        if (grp == 0) MIL_STAMP(10);
-        // ---- last inverse stages, real-space operation, first forward stages: radix 2 (sub-transforms of length 2 M, split
-        // over the lanes l and l + 32) and radix 8 (length NH) on 8 elements per lane, two passes of 8 rows
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            float2 *p = sp + 8 * ps;
-            float2 t[8], mm[8];
-            // twiddle addresses and the radix-2 twiddle are recomputed / re-read per pass: hoisted out of the trip loop they
-            // cost ~20 registers, which the compiler then spills
-            int si_l = si, wi_l = 8 * sbi;
-            asm volatile("" : "+v"(si_l), "+v"(wi_l));
-            const float2 wl = tw[wi_l];  // w_2M^sbi
-#pragma unroll
-            for (int r = 0; r < 8; ++r) mm[r] = pre[8 * ps + r];
-            if (ps == 0) {  // the second pass's M / E
-#pragma unroll
-                for (int r = 0; r < 8; ++r) pre[8 + r] = buf_load2<Aux<STREAM>::ld_real>(rr, svoff, rsoff + spass + r * srj);
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) t[c] = p[c * SCS];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);  // lower lane: both halves of blocks 0..3, upper: of 4..7
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float2 u = t[c], w = tw_mul<+1>(t[c + 4], wl);
-                t[c] = c_add(u, w);
-                t[c + 4] = c_sub(u, w);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);  // lane h: half h of blocks 0..7
-#pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = tw_mul<+1>(t[k], tw[si_l * k]);
-            dft8<+1>(t);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float2 m = mm[j];
-                if (MODE == kXRatio) {  // div3Dkernel: T = A / T (unguarded)
-                    t[j] = make_float2(xy_div(m.x, t[j].x), xy_div(m.y, t[j].y));
-                } else {  // multi3Dkernel + maxvalue3Dgpukernel: E = max(E * T, eps)
-                    float2 e = make_float2(m.x * t[j].x, m.y * t[j].y);
-                    e.x = (e.x > a.eps) ? e.x : a.eps;
-                    e.y = (e.y > a.eps) ? e.y : a.eps;
-                    buf_store2<Aux<STREAM>::st_real>(rr, svoff, rsoff + ps * spass + j * srj, e);
-                    t[j] = e;
-                }
-            }
-            if constexpr (MODE != kXUpdateLast) {
-                dft8<-1>(t);
-                asm volatile("" : "+v"(si_l));
-#pragma unroll
-                for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], tw[si_l * k]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float2 u = t[c], w = t[c + 4];
-                    t[c] = c_add(u, w);
-                    t[c + 4] = tw_mul<-1>(c_sub(u, w), wl);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) swap32(t[c], t[c + 4]);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) p[c * SCS] = t[c];
-            }
-        }
-        if (grp == 0) MIL_STAMP(11);
-        if constexpr (MODE == kXUpdateLast) {
-#pragma unroll
-            for (int m = 0; m < NV - RB; ++m) v[m] = v[m + RB];
-#pragma unroll
-            for (int i = 0; i < PARK; ++i) v[NV - RB + i] = park[i * NH];
-            lds_barrier();  // the next fold overwrites the tile
-            continue;
-        }
-        lds_barrier();
-        xy_stage_m<NH, false, -1>(tile, tw);  // DIF stage(s) of length M
-        lds_barrier();
-        if (grp == 0) MIL_STAMP(12);
-        // The queue moves up by one trip; then the Hermitian split back into this thread's column: each lane picks up its
-        // element Z[k] / Z[NH-k], the pair swaps.
-#pragma unroll
-        for (int m = 0; m < NV - RB; ++m) v[m] = v[m + RB];
-#pragma unroll
-        for (int i = 0; i < PARK; ++i) v[NV - RB + i] = park[i * NH];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const float2 own = tile[pzs + r], oth = swap_pair(own);
-            const float2 A = c_add(own, oth), B = c_sub(own, oth);
-            float2 o = make_float2(0.5f * A.x + fh1 * A.y + fh2 * B.x, 0.5f * B.y - fh1 * B.x + fh2 * A.y);
-            if (tid < 2) o = tid == 0 ? make_float2(own.x + own.y, own.x - own.y)  // (X[0], X[NH]), both real
-                                      : make_float2(own.x, -own.y);                // X[NH/2] = conj(Z[NH/2])
-            if (r < RB - PARK) v[64 - RB + r] = o;
-            else park[(r - (RB - PARK)) * NH] = o;
-        }
-        if (grp == 0) MIL_STAMP(13);
-        lds_barrier();  // the next fold overwrites the tile
-        if (grp == 0) MIL_STAMP(2);
-    }
-    MIL_STAMP(3);
-    if constexpr (MODE == kXUpdateLast) return;
-#pragma unroll
-    for (int i = 0; i < PARK; ++i) v[NV + i] = park[i * NH];
-    // ---- y forward head: DIF stages L = NY (over j1) and L = NY / 8 (over j2)
-#pragma unroll
-    for (int j2 = 0; j2 < 8; ++j2) {
-        float2 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = v[j2 + 8 * k];
-        dft8<-1>(t);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twy[(n2 + T * j2) * k]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[j2 + 8 * k] = t[k];
-    }
-#pragma unroll
-    for (int j1 = 0; j1 < 8; ++j1) {
-        float2 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = v[k + 8 * j1];
-        dft8<-1>(t);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t[k] = tw_mul<-1>(t[k], twy[n2 * k * 8]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k + 8 * j1] = t[k];
-    }
-    MIL_STAMP(4);
-#pragma unroll
-    for (int m = 0; m < 64; ++m) buf_store2<Aux<STREAM>::st_spec>(rs, voff, soff0 + m * rstep, v[m]);
-    MIL_STAMP(5);
-#ifdef MIL_FX_STAMPS
-    if (a.stamps) {
-        __builtin_amdgcn_s_waitcnt(0);
-        MIL_STAMP(6);
-    }
-#endif
-}
+#include "fft2p_dev.h"
 
 unsigned long long *g_stamps = nullptr;  // set through mil_fx_set_stamps (timing experiments)
 
 }  // namespace
 
+namespace {
+// boxes this file's instantiations (NH and NY compile-time constants) cover: nx, ny powers of two ...
+bool static_xy(Dims b) {
+    return (b.nx == 256 || b.nx == 512 || b.nx == 1024) && (b.ny == 1024 || b.ny == 512 || b.ny == 256 || b.ny == 128);
+}
+// ... and ny = 512, nz = 256 (the register yz kernel); every other (ny, nz) runs the LDS kernel of fft2p_any_yz.hip
+bool static_yz(Dims b) { return static_xy(b) && b.ny == kNY && b.nz == kNZ; }
+any::Box any_box(Dims b, int xs, int pitch) { return any::Box{(int)b.nx, (int)b.ny, (int)b.nz, xs, pitch}; }
+}  // namespace
+
+// nx = 192 .. 1024 and ny = 128 .. 1024 in multiples of 64; nz a multiple of 64 with (ny / 64) x nz <= 2048 -- the yz tile of
+// ny / 64 rows x 8 columns x nz must fit the LDS (4-column tiles, 32-byte row segments, were measured SLOWER than the classic
+// sequence: 1024 x 1024 x 256, 172 against 201 it/s, profiles/r03/bench_box_ny1024.txt) -- or 512 x 256 (register yz kernel,
+// nx a power of two).  Powers of two run this file's instantiations, everything else those of fft2p_any_*.hip.
 bool ConvPlan::two_pass_supported(Dims b) {
-    if (b.nx != 256 && b.nx != 512 && b.nx != 1024) return false;
-    if (b.ny != 1024 && b.ny != 512 && b.ny != 256 && b.ny != 128) return false;
-    const long long t = b.ny / 64;
-    if (b.ny == kNY && b.nz == kNZ) return true;                              // register yz kernel
-    if (b.nz != 64 && b.nz != 128 && b.nz != 256 && b.nz != 512) return false;
-    // ny = 1024: LDS-resident yz kernel on 16- / 8-column tiles.  nz = 256 would need 4-column tiles (32-byte row segments):
-    // measured SLOWER than the classic sequence (1024 x 1024 x 256: 172 against 201 it/s, profiles/r03/bench_box_ny1024.txt)
-    if (b.ny == 1024) return b.nz <= 128;
-    return t * b.nz <= 1024;               // LDS-resident yz kernel, 16-column tiles
+    if (b.nx % 64 || b.nx < 192 || b.nx > 1024 || b.ny % 64 || b.ny < 128 || b.ny > 1024) return false;
+    if (static_yz(b)) return true;
+    return b.nz % 64 == 0 && b.nz >= 64 && b.nz <= 1024 && (b.ny / 64) * b.nz <= 2048;
 }
 
 void ConvPlan::init_two_pass() {
@@ -929,18 +85,17 @@ void ConvPlan::init_two_pass() {
             pairs.push_back((unsigned short)nb);
         }
     }
-    {
-        std::vector<float2> ty((size_t)ny);
-        MIL_HIP(hipMemcpy(ty.data(), tw_y_.get(), ty.size() * sizeof(float2), hipMemcpyDeviceToHost));
-        const size_t off = ny == 128 ? offsetof(TwYTables, w128) : ny == 256 ? offsetof(TwYTables, w256)
-                         : ny == 512 ? offsetof(TwYTables, w512) : offsetof(TwYTables, w1024);
-        MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_y), ty.data(), ty.size() * sizeof(float2), off));
-        if (ny == kNY && box_.nz == kNZ) {  // the register yz kernel reads its z twiddles from constant memory
-            std::vector<float2> tz((size_t)kNZ);
-            MIL_HIP(hipMemcpy(tz.data(), tw_z_.get(), tz.size() * sizeof(float2), hipMemcpyDeviceToHost));
-            MIL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tw_z), tz.data(), tz.size() * sizeof(float2)));
-        }
+    xy_any_ = !static_xy(box_);
+    yz_any_ = !static_yz(box_);
+    if (const char *e = getenv("MIL_FX_ANY")) {  // diagnostics: 1 / 2 / 3 = run-time-geometry xy / yz / both kernels wherever they cover the box
+        const any::Box ab = any_box(box_, xs_, pitch_);
+        if ((atoi(e) & 1) && any::xy_covers(ab)) xy_any_ = true;
+        if ((atoi(e) & 2) && any::yz_covers(ab)) yz_any_ = true;
     }
+    // every translation unit that launches kernels for this box fills its own constant tables
+    fill_tw_tables(tw_y_.get(), ny, tw_z_.get(), (int)box_.nz);
+    if (xy_any_) any::xy_fill_tables(tw_y_.get(), ny);
+    if (yz_any_) any::yz_fill_tables(tw_y_.get(), ny);
     n_pairs_ = (int)pairs.size() / 2;
     pairs_.alloc(pairs.size());
     MIL_HIP(hipMemcpy(pairs_.get(), pairs.data(), pairs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
@@ -965,6 +120,10 @@ void with_nh(long long nx, F &&f) {
 void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
     if (part < 0 || part > 3) throw Error(-1, "y_part: unknown part");
+    if (any::y_part_covers((int)box_.ny)) {
+        any::y_part(any_box(box_, xs_, pitch_), S, tw_y_.get(), col0_.get(), part, s);
+        return;
+    }
     PartArgs a;
     a.S = S; a.tw = tw_y_.get(); a.col0 = (part == 2) ? col0_.get() : nullptr;
     a.row_stride = pitch_; a.outer_stride = (long long)box_.ny * pitch_; a.groups = xs_ / kW;
@@ -986,40 +145,25 @@ void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
 
 void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
+    if (yz_any_) {
+        any::yz_conv(any_box(box_, xs_, pitch_), S, otf, neg_y_.get(), neg_z_.get(), pairs_.get(), n_pairs_, tw_z_.get(), s);
+        return;
+    }
     YzArgs a;
     a.S = S; a.otf = otf; a.otf_q = otf + (size_t)xs_ * box_.ny * box_.nz;
     a.neg_y = neg_y_.get(); a.neg_z = neg_z_.get(); a.pairs = pairs_.get();
     a.pair_blocks = n_pairs_;
     a.stamps = g_stamps;
-    const dim3 block(kYzThreads);
-    auto grid_for = [&](int cols) { return dim3((unsigned)(64 * (xs_ / cols) + n_pairs_)); };  // 64 blocks of T rows, whatever ny is
-    const float2 *twz = tw_z_.get();
-    const int ny = (int)box_.ny, nz = (int)box_.nz;
-    // Tiles are 8 columns wide wherever that leaves a workgroup enough work (T x nz >= 512): half the LDS per workgroup, so a CU
-    // holds two (or four) whose load / transform / store phases overlap, and the two halves of each 128-byte row segment go to
-    // workgroups t and t + 8 (same XCD, same L2) so HBM still moves whole lines.  Measured against unpaired 16-column tiles
-    // (profiles/r03/bench_box_paired8.txt): +5 % at 512 x 512 x 256 (register kernel), +9..13 % at T x nz = 1024, +3..5 % at 512;
-    // -1..+2 % below that, where 16 columns stay.  Unpaired 8-column tiles gain nothing (the 64-byte segments cost what the
-    // overlap wins: bench_box_narrow.txt).
+    a.pitch = pitch_; a.groups = xs_ / kW; a.otf_stream = 0;
+    // The register kernel of 512 x 256.  Its tiles are 8 columns wide: half the LDS per workgroup, so a CU holds two whose load /
+    // exchange / store phases overlap, and the two halves of each 128-byte row segment go to workgroups t and t + 8 (same XCD, same
+    // L2) so HBM still moves whole lines (profiles/r03/bench_box_paired8.txt: +5 % against unpaired 16-column tiles; unpaired
+    // 8-column tiles gain nothing -- the 64-byte segments cost what the overlap wins: bench_box_narrow.txt).
+    const dim3 grid((unsigned)(64 * (xs_ / 8) + n_pairs_));  // 64 blocks of 8 rows
     with_nh(box_.nx, [&](auto nh_tag) {
         constexpr int NH = decltype(nh_tag)::value;
-#define MIL_YZ(NY, NZ, COLS, PAIR) \
-    else if (ny == NY && nz == NZ) hipLaunchKernelGGL((yz_lds_kernel<NY, NZ, NH, COLS, PAIR>), grid_for(COLS), block, 0, s, a, twz);
-        if (ny == kNY && nz == kNZ && stream_) hipLaunchKernelGGL((yz_conv_kernel<NH, 8, true>), grid_for(8), dim3(256), 0, s, a);
-        else if (ny == kNY && nz == kNZ) hipLaunchKernelGGL((yz_conv_kernel<NH, 8, false>), grid_for(8), dim3(256), 0, s, a);
-        MIL_YZ(1024, 128, 8, true)
-        MIL_YZ(1024, 64, 8, true)
-        MIL_YZ(512, 128, 8, true)
-        MIL_YZ(512, 64, 8, true)
-        MIL_YZ(256, 256, 8, true)
-        MIL_YZ(256, 128, 8, true)
-        MIL_YZ(256, 64, 16, false)
-        MIL_YZ(128, 512, 8, true)
-        MIL_YZ(128, 256, 8, true)
-        MIL_YZ(128, 128, 16, false)
-        MIL_YZ(128, 64, 16, false)
-        else throw Error(-1, "yz_conv: box outside the two-pass path");
-#undef MIL_YZ
+        if (stream_) hipLaunchKernelGGL((yz_conv_kernel<NH, 8, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((yz_conv_kernel<NH, 8, false>), grid, dim3(256), 0, s, a);
     });
     MIL_HIP(hipGetLastError());
 }
@@ -1028,11 +172,16 @@ void ConvPlan::xy_pass(XMode mode, float2 *S, float *E, const float *M, float ep
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
     if (!S || (mode == kXRatio ? !M : !E)) throw Error(-1, "xy_pass: missing operand");
     if (mode != kXRatio && mode != kXUpdate && mode != kXUpdateLast) throw Error(-1, "xy_pass: mode must be ratio / update");
+    if (xy_any_) {
+        any::xy_pass(any_box(box_, xs_, pitch_), (int)mode, S, E, M, tw_x_.get(), eps, stream_, s);
+        return;
+    }
     XyArgs a;
     a.S = S; a.E = E; a.M = M; a.tw_x = tw_x_.get(); a.eps = eps;
     a.spec_bytes = (long long)pitch_ * box_.ny * box_.nz * 8;
     a.real_bytes = (long long)box_.nx * box_.ny * box_.nz * 4;
     a.stamps = (g_stamps && mode == kXRatio) ? g_stamps + 2048 * 16 : nullptr;
+    a.t = (int)box_.ny / 64;
     const int T = (int)box_.ny / 64;
     const dim3 grid((unsigned)(box_.nz * T));
     with_nh(box_.nx, [&](auto nh_tag) {

@@ -177,9 +177,98 @@ __device__ __forceinline__ void dft_odd(float2 *v) {
     }
 }
 
+
+// cos / sin(2*pi*k/R) for the composite radices (two factors, 6 .. 15)
+template <int R>
+struct CompTable;
+template <>
+struct CompTable<6> {
+    static constexpr float c[6] = {1.0f, 0.5000000000000001f, -0.4999999999999998f, -1.0f, -0.5000000000000004f, 0.5000000000000001f};
+    static constexpr float s[6] = {0.0f, 0.8660254037844386f, 0.8660254037844387f, 0.0f, -0.8660254037844384f, -0.8660254037844386f};
+};
+template <>
+struct CompTable<9> {
+    static constexpr float c[9] = {1.0f, 0.766044443118978f, 0.17364817766693041f, -0.4999999999999998f, -0.9396926207859083f, -0.9396926207859084f, -0.5000000000000004f, 0.17364817766692997f, 0.7660444431189778f};
+    static constexpr float s[9] = {0.0f, 0.6427876096865393f, 0.984807753012208f, 0.8660254037844387f, 0.3420201433256689f, -0.34202014332566866f, -0.8660254037844384f, -0.9848077530122081f, -0.6427876096865396f};
+};
+template <>
+struct CompTable<10> {
+    static constexpr float c[10] = {1.0f, 0.8090169943749475f, 0.30901699437494745f, -0.30901699437494734f, -0.8090169943749473f, -1.0f, -0.8090169943749476f, -0.30901699437494756f, 0.30901699437494723f, 0.8090169943749473f};
+    static constexpr float s[10] = {0.0f, 0.5877852522924731f, 0.9510565162951535f, 0.9510565162951536f, 0.5877852522924732f, 0.0f, -0.587785252292473f, -0.9510565162951535f, -0.9510565162951536f, -0.5877852522924734f};
+};
+template <>
+struct CompTable<12> {
+    static constexpr float c[12] = {1.0f, 0.8660254037844387f, 0.5000000000000001f, 0.0f, -0.4999999999999998f, -0.8660254037844387f, -1.0f, -0.8660254037844388f, -0.5000000000000004f, 0.0f, 0.5000000000000001f, 0.8660254037844384f};
+    static constexpr float s[12] = {0.0f, 0.49999999999999994f, 0.8660254037844386f, 1.0f, 0.8660254037844387f, 0.49999999999999994f, 0.0f, -0.4999999999999997f, -0.8660254037844384f, -1.0f, -0.8660254037844386f, -0.5000000000000004f};
+};
+template <>
+struct CompTable<14> {
+    static constexpr float c[14] = {1.0f, 0.9009688679024191f, 0.6234898018587336f, 0.22252093395631445f, -0.22252093395631434f, -0.6234898018587335f, -0.900968867902419f, -1.0f, -0.9009688679024191f, -0.6234898018587337f, -0.2225209339563146f, 0.22252093395631334f, 0.6234898018587334f, 0.9009688679024194f};
+    static constexpr float s[14] = {0.0f, 0.4338837391175581f, 0.7818314824680298f, 0.9749279121818236f, 0.9749279121818236f, 0.7818314824680299f, 0.43388373911755823f, 0.0f, -0.433883739117558f, -0.7818314824680297f, -0.9749279121818236f, -0.9749279121818238f, -0.7818314824680299f, -0.4338837391175575f};
+};
+template <>
+struct CompTable<15> {
+    static constexpr float c[15] = {1.0f, 0.9135454576426009f, 0.6691306063588582f, 0.30901699437494745f, -0.10452846326765333f, -0.4999999999999998f, -0.8090169943749473f, -0.9781476007338057f, -0.9781476007338057f, -0.8090169943749476f, -0.5000000000000004f, -0.10452846326765423f, 0.30901699437494723f, 0.6691306063588585f, 0.913545457642601f};
+    static constexpr float s[15] = {0.0f, 0.40673664307580015f, 0.7431448254773941f, 0.9510565162951535f, 0.9945218953682734f, 0.8660254037844387f, 0.5877852522924732f, 0.20791169081775931f, -0.20791169081775907f, -0.587785252292473f, -0.8660254037844384f, -0.9945218953682733f, -0.9510565162951536f, -0.743144825477394f, -0.40673664307580015f};
+};
+
+// a * exp(SIGN * 2 pi i m / R), m known at compile time
+template <int R, int SIGN, int M>
+__device__ __forceinline__ float2 mul_wr(float2 a) {
+    constexpr float c = CompTable<R>::c[M % R], s = CompTable<R>::s[M % R];
+    if constexpr (c == 1.0f) return a;
+    else if constexpr (c == -1.0f) return make_float2(-a.x, -a.y);
+    else if constexpr (c == 0.0f && s == 1.0f) return rot90<SIGN>(a);
+    else if constexpr (c == 0.0f && s == -1.0f) return rot90<-SIGN>(a);
+    else return a * make_float2(c, c) + rot90<SIGN>(a) * make_float2(s, s);
+}
+
+template <int R, int SIGN>
+__device__ __forceinline__ void dft_small(float2 *v);
+
+// R = R1 x R2 points (6 = 2 x 3, 9 = 3 x 3, 10 = 2 x 5, 12 = 4 x 3, 14 = 2 x 7, 15 = 3 x 5), natural order in and out:
+// n = R2 n1 + n2, k = k1 + R1 k2; R2 transforms of length R1, the twiddles w_R^(n2 k1), R1 transforms of length R2.
+template <int R, int R1, int SIGN, int N2, int K1>
+__device__ __forceinline__ void comp_twiddle(float2 *y) {
+    if constexpr (N2 < R / R1) {
+        if constexpr (K1 < R1) {
+            y[N2 * R1 + K1] = mul_wr<R, SIGN, N2 * K1>(y[N2 * R1 + K1]);
+            comp_twiddle<R, R1, SIGN, N2, K1 + 1>(y);
+        } else {
+            comp_twiddle<R, R1, SIGN, N2 + 1, 1>(y);
+        }
+    }
+}
+template <int R, int SIGN>
+__device__ __forceinline__ void dft_comp(float2 *v) {
+    constexpr int R1 = (R % 4 == 0) ? 4 : (R % 2 == 0) ? 2 : 3, R2 = R / R1;
+    float2 y[R];  // y[n2][k1]
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) {
+        float2 t[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[R2 * n1 + n2];
+        dft_small<R1, SIGN>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) y[n2 * R1 + k1] = t[k1];
+    }
+    comp_twiddle<R, R1, SIGN, 1, 1>(y);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        float2 t[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) t[n2] = y[n2 * R1 + k1];
+        dft_small<R2, SIGN>(t);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+    }
+}
+constexpr bool is_comp_radix(int R) { return R == 6 || R == 9 || R == 10 || R == 12 || R == 14 || R == 15; }
+
 template <int R, int SIGN>
 __device__ __forceinline__ void dft_small(float2 *v) {
-    if constexpr (R == 16) dft16<SIGN>(v);
+    if constexpr (is_comp_radix(R)) dft_comp<R, SIGN>(v);
+    else if constexpr (R == 16) dft16<SIGN>(v);
     else if constexpr (R == 8) dft8<SIGN>(v);
     else if constexpr (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
     else if constexpr (R == 2) dft2<SIGN>(v);
@@ -205,7 +294,7 @@ __device__ __forceinline__ void fft_stage(float2 *__restrict__ tile, const float
         const int c = idx % W;
         const int b = idx / W;
         const int blk = b / M, i = b % M;
-        float2 *p = tile + (blk * L + i) * WP + c + (SKEW ? (blk * L) / SKEW : 0);
+        float2 *p = tile + (blk * L + i) * WP + c + (SKEW ? (blk * L) / (SKEW ? SKEW : 1) : 0);
         float2 v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = p[j * M * WP];

@@ -58,9 +58,10 @@ public:
     // test aid: private OTF order -> natural [nz][ny][nx/2+1] (rocFFT / numpy rfftn order)
     void otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const;
 
-    // ---- two-pass path (csrc/fft2p.hip; 512 x 512 x {256, 128, 64} boxes): the last radix-8 stage of the y transform rides in the
-    // z kernel and its first two in the x kernel, so a half view update is  yz_conv | xy_pass  instead of
-    // y | z_conv | y^-1 | x_pass.  Same spectrum positions and OTFs as the classic kernels.
+    // ---- two-pass path (csrc/fft2p.hip, fft2p_any_*.hip; nx, ny multiples of 64 from 192 / 128, (ny / 64) x nz <= 2048): the
+    // tail of the y transform (its stages of length ny / 64) rides in the z kernel and its first two radix-8 stages in the x
+    // kernel, so a half view update is  yz_conv | xy_pass  instead of  y | z_conv | y^-1 | x_pass.  Same spectrum positions
+    // and OTFs as the classic kernels.
     static bool two_pass_supported(Dims box);
     bool two_pass() const { return two_pass_; }
     // partial classic y passes: 0 forward head (stages longer than 8), 1 inverse head, 2 forward tail (the stage of
@@ -84,6 +85,7 @@ private:
     void init_two_pass();
     bool two_pass_ = false;
     bool stream_ = false;  // fft2p.hip: non-temporal hints on OTF / image / estimate accesses (large boxes)
+    bool xy_any_ = false, yz_any_ = false;  // the box runs the run-time-geometry kernels of fft2p_any_xy.hip / fft2p_any_yz.hip
     DeviceBuffer<unsigned short> pairs_;  // two-pass path: pairs of 8-row blocks holding ky and -ky
     int n_pairs_ = 0;
 };

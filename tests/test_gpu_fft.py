@@ -130,12 +130,23 @@ _YZ = [(128, 1024), (64, 1024),                           # (nz, ny): y tail T =
        (256, 256), (128, 256), (64, 256),                 # T = 4
        (512, 128), (256, 128), (128, 128), (64, 128)]     # T = 2
 TWO_PASS_BOXES = [(nz, ny, nx) for nx in (512, 256, 1024) for (nz, ny) in _YZ]  # (nz, ny, nx)
+# Boxes of csrc/fft2p_any_*.hip (the 64 k extents snapTransformSize produces, reference src/api_subfunc.cu:57-87): every
+# nx = 192 .. 1024 (x transforms of 16 x 6 .. 16 x 32, half waves idle for nx / 2 = 96, 160, 224 ...), every y tail
+# T = ny / 64 = 2 .. 16 (one- and two-stage tails), every nz = 64 .. 1024 in multiples of 64 (radices 3 .. 13 in z), 16- and
+# 8-column yz tiles up to T x nz = 2048, powers of two mixed with the others.
+ANY_BOXES = [(256, 384, 384), (128, 320, 448),            # the two boxes of the round-4 review
+             (64, 192, 192), (192, 192, 320), (64, 448, 576), (128, 576, 640), (192, 640, 704), (128, 704, 768),
+             (64, 768, 832), (128, 832, 896), (64, 896, 960), (64, 960, 1024),
+             (320, 384, 256), (384, 320, 512), (512, 256, 512), (1024, 128, 256), (256, 512, 384), (128, 1024, 320),
+             (448, 256, 192), (640, 192, 384), (576, 128, 448),
+             (704, 128, 192), (768, 128, 192), (832, 128, 192), (896, 128, 192), (960, 128, 192)]
 
 
-@pytest.mark.parametrize("shape", TWO_PASS_BOXES, ids=lambda s: "x".join(str(v) for v in s[::-1]))
+@pytest.mark.parametrize("shape", TWO_PASS_BOXES + ANY_BOXES, ids=lambda s: "x".join(str(v) for v in s[::-1]))
 def test_two_pass_kernels_agree_with_the_classic_sequence(dev, monkeypatch, shape):
     """csrc/fft2p.hip on every box it covers (nx = 256 / 512 / 1024 = x transforms of 16 x 8 / 16 / 32; ny = 1024 / 512 / 256 /
-    128 = y tails of 16 / 8 / 4 / 2 rows; every nz whose yz tile fits the LDS, plus ... x 512 x 256 on register tiles): the yz kernel
+    128 = y tails of 16 / 8 / 4 / 2 rows; every nz whose yz tile fits the LDS, plus ... x 512 x 256 on register tiles) and a
+    sample of the boxes of csrc/fft2p_any_*.hip that touches every instantiated nx, y tail and nz: the yz kernel
     alone (MIL_FX_TWOPASS=1, partial classic y
     passes around it), the xy kernel alone (2) and both (3, the default on these boxes) against the classic four-kernel
     half update (0) -- 3 single-view and 2 dual-view iterations on the same inputs, the last one through the
