@@ -144,6 +144,7 @@ DeconEngine::DeconEngine(Dims fft_box, hipStream_t stream, int backend) : box_(f
             if (plan_->two_pass()) {  // MIL_FX_TWOPASS: 0 classic, 1 z kernel only, 2 x kernel only, 3 both
                 const char *tp = getenv("MIL_FX_TWOPASS");
                 two_pass_ = tp ? (atoi(tp) & 3) : kTwoPassDefault;
+                plan_->set_yz_otf_layout(two_pass_ & 1);  // OTFs tiled per yz workgroup
             }
         }
         else fft_ = new Fft3D(box_, stream_);
@@ -203,7 +204,13 @@ void DeconEngine::gen_otf(float2 *d_otf, const float *d_psf, Dims P, bool flip, 
 }
 
 void DeconEngine::convolve(float *out, const float *in, const float2 *otf) {
-    if (plan_) {
+    if (plan_ && plan_->yz_otf_layout()) {  // the engine's OTFs are tiled for the yz kernel: y head | yz_conv | y head^-1
+        plan_->x_pass(fx::kXForward, S_.get(), in, nullptr, nullptr, 0.f, stream_);
+        plan_->y_part(S_.get(), 0, stream_);
+        plan_->yz_conv(S_.get(), otf, stream_);
+        plan_->y_part(S_.get(), 1, stream_);
+        plan_->x_pass(fx::kXInverse, S_.get(), nullptr, out, nullptr, 0.f, stream_);
+    } else if (plan_) {
         plan_->x_pass(fx::kXForward, S_.get(), in, nullptr, nullptr, 0.f, stream_);
         plan_->y_pass(S_.get(), false, stream_);
         plan_->z_conv(S_.get(), otf, stream_);

@@ -52,6 +52,8 @@ struct ColArgs {
     float2 *col0;
     int col0_stride;  // ny
     int ablate;       // timing experiments only (MIL_FX_ABLATE & 16: skip the OTF product, & 32: skip both z transforms)
+    int otf_cols;     // kColToOtf: width of the OTF's column groups, [ky][group][kz][otf_cols] (16 = this file's own tiling; 8 / 4 = one
+                      // block per workgroup of the two-pass yz kernels, see ConvPlan::set_yz_otf_layout)
 };
 
 template <int N, int NT, int MODE>
@@ -132,7 +134,18 @@ __global__ __launch_bounds__(NT) void col_kernel(ColArgs a) {
             }
             lds_barrier();
         }
-        tile_store<N, NT>(tile, a.otf_out + otf_tile, kW);
+        if (a.otf_cols == kW) {
+            tile_store<N, NT>(tile, a.otf_out + otf_tile, kW);
+        } else {  // the 16 columns of this tile as 16 / otf_cols narrower groups, [kz][otf_cols] each
+            const int oc = a.otf_cols;
+            float2 *dst = a.otf_out + otf_tile;  // the groups of this (ky, 16-column group) follow each other: same N * 16 elements
+            for (int idx = (int)threadIdx.x; idx < N * 8; idx += NT) {
+                const int kz = idx >> 3, c2 = 2 * (idx & 7);
+                const float2 *q = tile + kz * kWP + c2;
+                const float2 x = q[0], y = q[1];
+                *reinterpret_cast<float4 *>(dst + ((long long)(c2 / oc) * N + kz) * oc + c2 % oc) = make_float4(x.x, x.y, y.x, y.y);
+            }
+        }
         return;
     }
     if constexpr (MODE == kColConv) {
@@ -330,18 +343,18 @@ __global__ __launch_bounds__(kNT) void x_kernel(XArgs a) {
 // ---------------------------------------------------------------------------
 __global__ void otf_to_natural_kernel(float2 *__restrict__ nat, const float2 *__restrict__ otf,
                                       const float2 *__restrict__ otf_q, const unsigned short *__restrict__ freq_y,
-                                      const unsigned short *__restrict__ freq_z, int nxh1, int ny, int nz, int groups) {
-    // one thread per private element (ky_s, g, kz_s, c)
-    const long long total = (long long)ny * groups * nz * kW;
+                                      const unsigned short *__restrict__ freq_z, int nxh1, int ny, int nz, int groups, int cols) {
+    // one thread per private element (ky_s, g, kz_s, c): `groups` column groups of `cols` columns
+    const long long total = (long long)ny * groups * nz * cols;
     const int nh = nxh1 - 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % kW);
-        long long r = i / kW;
+        const int c = (int)(i % cols);
+        long long r = i / cols;
         const int pz = (int)(r % nz);
         r /= nz;
         const int g = (int)(r % groups);
         const int py = (int)(r / groups);
-        const int col = g * kW + c;  // packed / mirrored-pair column order of the x pass
+        const int col = g * cols + c;  // packed / mirrored-pair column order of the x pass
         if (col >= nh) continue;
         float2 *row = nat + ((long long)freq_z[pz] * ny + freq_y[py]) * nxh1;
         const float2 v = otf[i];
@@ -561,10 +574,12 @@ void ConvPlan::y_pass(float2 *S, bool inverse, hipStream_t s, bool reverse) cons
     a.mode = inverse ? kColInverse : kColForward;
     a.reverse = reverse ? 1 : 0;
     a.ablate = 0;
+    a.otf_cols = kW;
     dispatch_col((int)box_.ny, a, (long long)a.groups * box_.nz, s);
 }
 
 void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s, bool reverse) const {
+    if (otf_cols_ != kW) throw Error(-1, "z_conv: this plan's OTFs are tiled for the two-pass yz kernel (set_yz_otf_layout)");
     ColArgs a;
     a.S = S; a.otf = otf; a.otf_out = nullptr; a.tw = tw_z_.get();
     a.partner = neg_y_.get(); a.neg = neg_z_.get();
@@ -576,6 +591,7 @@ void ConvPlan::z_conv(float2 *S, const float2 *otf, hipStream_t s, bool reverse)
     a.mode = kColConv;
     a.reverse = reverse ? 1 : 0;
     a.ablate = ablate_;
+    a.otf_cols = kW;
     dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
 }
 
@@ -591,6 +607,7 @@ void ConvPlan::z_forward_to_otf(const float2 *S, float2 *otf, hipStream_t s) con
     a.mode = kColToOtf;
     a.reverse = 0;
     a.ablate = 0;
+    a.otf_cols = otf_cols_;
     dispatch_col((int)box_.nz, a, (long long)a.groups * box_.ny, s);
 }
 
@@ -598,7 +615,7 @@ void ConvPlan::otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s)
     const int nxh1 = (int)box_.nx / 2 + 1;
     hipLaunchKernelGGL(otf_to_natural_kernel, dim3(2048), dim3(256), 0, s, natural, otf,
                        otf + (size_t)xs_ * box_.ny * box_.nz, freq_y_.get(), freq_z_.get(), nxh1, (int)box_.ny,
-                       (int)box_.nz, xs_ / kW);
+                       (int)box_.nz, xs_ / otf_cols_, otf_cols_);
     MIL_HIP(hipGetLastError());
 }
 

@@ -69,6 +69,12 @@ bool ConvPlan::two_pass_supported(Dims b) {
     return b.nz % 64 == 0 && b.nz >= 64 && b.nz <= 1024 && (b.ny / 64) * b.nz <= 2048;
 }
 
+void ConvPlan::set_yz_otf_layout(bool on) {
+    if (on && !two_pass_) throw Error(-1, "set_yz_otf_layout: the box has no two-pass path");
+    yz_otf_ = on;
+    otf_cols_ = !on ? kW : yz_any_ ? any::yz_cols(any_box(box_, xs_, pitch_)) : 8;  // 8: the register kernel's tiles
+}
+
 void ConvPlan::init_two_pass() {
     if (!two_pass_supported(box_) || pitch_ != (int)box_.nx / 2 + kW || xs_ != (int)box_.nx / 2) return;
     const int ny = (int)box_.ny, T = ny / 64;
@@ -145,6 +151,7 @@ void ConvPlan::y_part(float2 *S, int part, hipStream_t s) const {
 
 void ConvPlan::yz_conv(float2 *S, const float2 *otf, hipStream_t s) const {
     if (!two_pass_) throw Error(-1, "two-pass path: unsupported box");
+    if (!yz_otf_) throw Error(-1, "yz_conv: this plan's OTFs are tiled for z_conv (set_yz_otf_layout)");
     if (yz_any_) {
         any::yz_conv(any_box(box_, xs_, pitch_), S, otf, neg_y_.get(), neg_z_.get(), pairs_.get(), n_pairs_, tw_z_.get(), s);
         return;

@@ -25,6 +25,7 @@ void xy_pass(const Box &b, int mode, float2 *S, float *E, const float *M, const 
 // ---- fft2p_any_yz.hip: y tail . z . OTF . z^-1 . y tail^-1 on LDS tiles for (ny / 64) x nz <= 2048, nz a multiple of 64;
 // the partial classic y passes (head / tail) for the 64 k extents
 bool yz_covers(const Box &b);
+int yz_cols(const Box &b);  // columns of a workgroup's tile = width of the OTF's column groups yz_conv expects
 void yz_fill_tables(const float2 *tw_y_dev, int ny);
 void yz_conv(const Box &b, float2 *S, const float2 *otf, const unsigned short *neg_y, const unsigned short *neg_z,
              const unsigned short *pairs, int n_pairs, const float2 *tw_z, hipStream_t s);

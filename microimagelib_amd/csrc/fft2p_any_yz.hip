@@ -102,6 +102,8 @@ bool yz_covers(const Box &b) {
     return (b.ny / 64) * b.nz <= kMaxTile;
 }
 
+int yz_cols(const Box &b) { return cols_for(b.ny / 64, b.nz); }
+
 void yz_fill_tables(const float2 *tw_y_dev, int ny) { fill_tw_tables(tw_y_dev, ny, nullptr, 0); }
 
 void yz_conv(const Box &b, float2 *S, const float2 *otf, const unsigned short *neg_y, const unsigned short *neg_z,
@@ -113,7 +115,8 @@ void yz_conv(const Box &b, float2 *S, const float2 *otf, const unsigned short *n
     a.pair_blocks = n_pairs;
     a.stamps = nullptr;
     a.pitch = b.pitch; a.groups = b.xs / kW;
-    a.otf_stream = 0;  // measured with the hint: 384 x 256 slower (132 -> 148 us), 512 x 256 and 576 x 128 5 % faster: not worth a rule
+    a.otf_stream = (long long)b.nx * b.ny * b.nz * 4 >= kStreamVolumeBytes;
+    if (const char *e = getenv("MIL_FX_STREAM")) a.otf_stream = e[0] == '1';
     if (!dispatch_yz(b.ny / 64, b.nz, a, tw_z, b.xs, s, std::make_integer_sequence<int, 15>{}))
         throw Error(-1, "two-pass path: no yz kernel for this (ny, nz)");
     MIL_HIP(hipGetLastError());

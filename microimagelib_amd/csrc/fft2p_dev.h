@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NT) void col_part_kernel(PartArgs a) {
 // ---------------------------------------------------------------------------
 struct YzArgs {
     float2 *S;
-    const float2 *otf;    // classic tiling [row][g][kz][16]
+    const float2 *otf;    // [row][column group][kz][columns of the calling kernel's tile] (ConvPlan::set_yz_otf_layout)
     const float2 *otf_q;  // [row][kz]
     const unsigned short *neg_y, *neg_z;
     const unsigned short *pairs;  // [pair][2]: row blocks holding ky and -ky (packed column)
@@ -233,7 +233,8 @@ __device__ __forceinline__ float2 swap_pair(float2 a) {
 // ---- packed DC/Nyquist column: G = F0 + i FN needs conj(G(-ky, -kz)), which lives in the row block of -ky.
 // One workgroup per pair of row blocks, 2 x T rows x NZ z of column 0 in LDS as tile[z][2 T + 1].  `tw`: w_NZ^k, any address
 // space the 512 threads may index freely.
-template <int NY, int NZ, int NH, int NT = 512>
+// OC: columns per group of the OTF tiling (= the calling kernel's tile width): column 0 of group 0 is element 0 of [kz][OC].
+template <int NY, int NZ, int NH, int OC, int NT = 512>
 __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *tile, const float2 *tw, int pair) {
     constexpr int T = NY / 64, C = 2 * T;  // rows per block = columns of the tile
     constexpr int PW = C, PWP = PW + 1;    // tile[z][PW + 1]
@@ -258,7 +259,7 @@ __device__ __forceinline__ void packed_column_block(const YzArgs &a, float2 *til
             const int prow = a.neg_y[row];
             const int pc = ((prow / T) == blk[0] ? 0 : T) + (prow % T);
             const float2 gk = tile[p * PWP + c], gp = tile[a.neg_z[p] * PWP + pc];
-            const float2 pv = a.otf[(((long long)row * kGroups) * NZ + p) * kW];
+            const float2 pv = a.otf[(((long long)row * kGroups * (kW / OC)) * NZ + p) * OC];
             const float2 qv = a.otf_q[(long long)row * NZ + p];
             r[i] = c_add(c_mul(gk, pv), c_mul(qv, make_float2(gp.x, -gp.y)));
         }
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
     constexpr int THREADS = 32 * COLS;           // COLS columns x 8 rows x 4 z-residues
     constexpr int kXchg = 4 * 8 * COLS + COLS;   // float2 between consecutive exchanged registers: 4 z-residues x 8 rows x COLS
                                                  // columns (+ COLS: the register slots a wave reads at once fall on different bank halves)
-    constexpr int kPitch = Geo<NH>::pitch, kGroups = Geo<NH>::groups;
+    constexpr int kPitch = Geo<NH>::pitch;
     constexpr long long kSpecBytes = (long long)kPitch * kNY * kNZ * 8, kOtfBytes = (long long)NH * kNY * kNZ * 8;
     // exchange buffer of one quarter (66 KB) + parking space (92 KB): registers are the scarce resource of this kernel,
     // every spilled one is HBM traffic
@@ -306,7 +307,6 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
             g = 2 * ((q % (NH / 128)) * 8 + (tt % 8)) + tt / 8;
             b = q / (NH / 128);
         }
-        const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // 16-column group of the OTF tiling, offset inside it
         // ownership 1: all z = za + 4m (m = j2 + 8 j1) of one (row j, column)
         const int col = lane & (COLS - 1), za = wave & 3, j = (lane / COLS) + (64 / COLS) * (wave >> 2);
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.S, kSpecBytes), ro = make_rsrc(a.otf, kOtfBytes);
@@ -317,15 +317,17 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
         // slot kk = kb + 8 (ka - 2q), column); lane sp of the pair holds rows sp, sp + 2, sp + 4, sp + 6 going in and the
         // row frequencies 4 sp .. 4 sp + 3 at the OTF product (the radix-8 row butterfly split over the pair)
         const int sp = tid & 1, scol = (tid >> 1) & (COLS - 1), skk = tid / (2 * COLS);
-        const unsigned ooff0 = (unsigned)((((8 * b) * kGroups + g16) * kNZ) * kW) * 8u;  // wave-uniform part (scalar offset)
-        const unsigned ovoff = (unsigned)((4 * sp * kGroups * kNZ + 4 * (skk & 7) + 32 * (skk >> 3)) * kW + c16 + scol) * 8u;  // row 4 sp, position 4 kb + 32 (ka - 2q)
+        // OTF: [ky][COLS-column group][kz][COLS] -- this workgroup's block of a row is kNZ * COLS contiguous values
+        constexpr int kOGroups = NH / COLS;
+        const unsigned ooff0 = (unsigned)((((8 * b) * kOGroups + g) * kNZ) * COLS) * 8u;  // wave-uniform part (scalar offset)
+        const unsigned ovoff = (unsigned)((4 * sp * kOGroups * kNZ + 4 * (skk & 7) + 32 * (skk >> 3)) * COLS + scol) * 8u;  // row 4 sp, position 4 kb + 32 (ka - 2q)
         float2 v[64], o[2][16];
         auto load_otf = [&](int q) {  // position kc + 4 kb + 32 ka of row frequency 4 sp + k
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc)
-                    o[q & 1][kc * 4 + k] = buf_load2<Aux<STREAM>::ld_otf>(ro, ovoff, ooff0 + (unsigned)((k * kGroups * kNZ + 64 * q + kc) * kW) * 8u);
+                    o[q & 1][kc * 4 + k] = buf_load2<Aux<STREAM>::ld_otf>(ro, ovoff, ooff0 + (unsigned)((k * kOGroups * kNZ + 64 * q + kc) * COLS) * 8u);
         };
         MIL_STAMP(0);
 #pragma unroll
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
 #endif
         return;
     }
-    packed_column_block<kNY, kNZ, NH, THREADS>(a, lds, twz, (int)blockIdx.x);
+    packed_column_block<kNY, kNZ, NH, COLS, THREADS>(a, lds, twz, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
     for (int k = tid; k < NZ; k += kYzThreads) tw[k] = tw_z[k];
     if ((int)blockIdx.x < a.pair_blocks) {
         lds_barrier();
-        packed_column_block<NY, NZ, NH>(a, tile, tw, (int)blockIdx.x);
+        packed_column_block<NY, NZ, NH, COLS>(a, tile, tw, (int)blockIdx.x);
         return;
     }
     const int GROUPS = kGroups * (kW / COLS);
@@ -534,7 +536,6 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
         g = SUB * (l % kGroups) + tt / 8;
         b = l / kGroups;
     }
-    const int g16 = (g * COLS) / kW, c16 = (g * COLS) % kW;  // the 16-column group of the OTF tiling, offset inside it
     float2 *base = a.S + (long long)(T * b) * kPitch + g * COLS;
     const long long zstride = (long long)NY * kPitch;
     // ---- load: NZ x T row segments
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
     float4 oreg[OPER];
     auto otf_piece = [&](int idx) {
         const int q = idx % QR, kz = (idx / QR) % NZ, row = idx / (QR * NZ);
-        const float4 *src = reinterpret_cast<const float4 *>(a.otf + ((((long long)(T * b + row) * kGroups + g16) * NZ + kz) * kW) + c16 + 2 * q);
+        const float4 *src = reinterpret_cast<const float4 *>(a.otf + ((((long long)(T * b + row) * GROUPS + g) * NZ + kz) * COLS) + 2 * q);
         if (a.otf_stream) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
@@ -732,11 +733,15 @@ struct XyArgs {
 
 // The x transform of length NH runs as NH = 16 x M: element k = a + 16 b (a < 16, b < M) of the half-length sequence sits at
 // position a * M + pos_M(b), where pos_M is the in-place order of the length-M sub-transforms.  Every trip of a stage
-// through the LDS costs the same whatever its radix, so M <= 16 is ONE stage (radix M in registers: 6 = 2 x 3, 10 = 2 x 5,
-// 12 = 4 x 3, 14 = 2 x 7 through dft_comp; pos_M the identity) and the longer ones are two: 18 = 6 x 3, 20 = 4 x 5, 22 = 2 x 11,
-// 24 = 8 x 3, 26 = 2 x 13, 28 = 4 x 7, 30 = 6 x 5, 32 = 8 x 4 (pos_M(b) = (b % R) (M / R) + b / R).  (Measured with the classic
-// schedule -- 12 = 4 . 3 in two trips -- the M = 12 kernel ran at 3.2 TB/s where M = 16 reaches 4.3.)
-constexpr int xy_radix(int L) { return L <= 16 ? L : (L == 18 || L == 30) ? 6 : pick_radix(L); }
+// through the LDS costs the same whatever its radix, and the kernel is bound by the latency of its trips, so the whole
+// length M = 6 .. 32 is ONE stage: radix M in registers (dft_comp: 12 = 4 x 3, 18 = 2 x 9, 24 = 4 x 6 ...; the primes 11, 13
+// by definition), pos_M the identity.  Measured at 128 x 512 x nx against the classic schedules (12 = 4 . 3, 18 = 2 . 3 . 3,
+// 32 = 8 . 4 in two or three trips): nx = 384 3.2 -> 4.1 TB/s, nx = 576 1.7 -> 2.5, nx = 1024 3.2 -> 3.4
+// (profiles/r05/twopass_any_variants.txt).  MIL_XY_ONE_STAGE_MAX (build-time) restores the staged form above it.
+#ifndef MIL_XY_ONE_STAGE_MAX
+#define MIL_XY_ONE_STAGE_MAX 32
+#endif
+constexpr int xy_radix(int L) { return L <= MIL_XY_ONE_STAGE_MAX ? L : (L == 18 || L == 30) ? 6 : pick_radix(L); }
 template <int M>
 __device__ __forceinline__ int xy_pos_m(int b) {
     if constexpr (M == 1) return 0;
@@ -781,14 +786,19 @@ __device__ __forceinline__ void xy_stage_m(float2 *tile, const float2 *tw) {
 //   * the fused radix-16 stage runs as radix 2 (across lanes l and l + 32) x radix 8 (in the lane): 8 + 8 instead of
 //     16 + 16 complex temporaries;
 //   * addresses and twiddles of the trip loop are recomputed per trip (hoisted, they were what got spilled).
-// From NH = 416 on (seven / eight waves per workgroup, 60 - 74 KB of tile) a CU holds ONE workgroup either way: two waves per
-// SIMD, no parking.  NH that is not a whole number of waves (96, 160, 224 ...) runs with the last half wave idle in the
-// column phases (threads = NH rounded up to 64) and 32 idle lane pairs in the fused stage.
+// Beyond NH = 256 (five to eight waves per workgroup, 40 - 74 KB of tile, radix-18 .. 32 LDS stages in registers) the kernel is
+// built for two waves per SIMD without parking: one workgroup per CU.  (Three waves per SIMD -- two workgroups of five or six
+// waves for NH = 288 .. 384 -- needed 76 - 100 bytes of scratch per lane and ran 10 - 20 % slower.)  NH that is not a whole
+// number of waves (96, 160, 224 ...) runs with the last half wave idle in the column phases (threads = NH rounded up to 64)
+// and 32 idle lane pairs in the fused stage.
+#ifndef MIL_XY_OCC3_MAX
+#define MIL_XY_OCC3_MAX 256
+#endif
 template <int NH>
 struct XyCfg {
     static constexpr int threads = (NH + 63) / 64 * 64;
-    static constexpr int occ = NH > 384 ? 2 : 3;
-    static constexpr int park = NH > 384 ? 0 : 8;
+    static constexpr int occ = NH > MIL_XY_OCC3_MAX ? 2 : 3;
+    static constexpr int park = NH > MIL_XY_OCC3_MAX ? 0 : 8;
 };
 
 // lanes l and l + 32 exchange (v_permlane32_swap):  a' = (a of the lower lanes | b of the LOWER lanes),

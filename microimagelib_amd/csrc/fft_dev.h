@@ -178,7 +178,7 @@ __device__ __forceinline__ void dft_odd(float2 *v) {
 }
 
 
-// cos / sin(2*pi*k/R) for the composite radices (two factors, 6 .. 15)
+// cos / sin(2*pi*k/R) for the composite radices (6 .. 15: two factors; 18 .. 32: the second factor composite again)
 template <int R>
 struct CompTable;
 template <>
@@ -211,6 +211,46 @@ struct CompTable<15> {
     static constexpr float c[15] = {1.0f, 0.9135454576426009f, 0.6691306063588582f, 0.30901699437494745f, -0.10452846326765333f, -0.4999999999999998f, -0.8090169943749473f, -0.9781476007338057f, -0.9781476007338057f, -0.8090169943749476f, -0.5000000000000004f, -0.10452846326765423f, 0.30901699437494723f, 0.6691306063588585f, 0.913545457642601f};
     static constexpr float s[15] = {0.0f, 0.40673664307580015f, 0.7431448254773941f, 0.9510565162951535f, 0.9945218953682734f, 0.8660254037844387f, 0.5877852522924732f, 0.20791169081775931f, -0.20791169081775907f, -0.587785252292473f, -0.8660254037844384f, -0.9945218953682733f, -0.9510565162951536f, -0.743144825477394f, -0.40673664307580015f};
 };
+template <>
+struct CompTable<18> {
+    static constexpr float c[18] = {1.0f, 0.9396926207859084f, 0.766044443118978f, 0.5000000000000001f, 0.17364817766693041f, -0.1736481776669303f, -0.4999999999999998f, -0.7660444431189779f, -0.9396926207859083f, -1.0f, -0.9396926207859084f, -0.7660444431189783f, -0.5000000000000004f, -0.17364817766693033f, 0.17364817766692997f, 0.49999999999999933f, 0.7660444431189778f, 0.9396926207859084f};
+    static constexpr float s[18] = {0.0f, 0.3420201433256687f, 0.6427876096865393f, 0.8660254037844386f, 0.984807753012208f, 0.984807753012208f, 0.8660254037844387f, 0.6427876096865395f, 0.3420201433256689f, 0.0f, -0.34202014332566866f, -0.6427876096865389f, -0.8660254037844384f, -0.984807753012208f, -0.9848077530122081f, -0.866025403784439f, -0.6427876096865396f, -0.3420201433256686f};
+};
+template <>
+struct CompTable<20> {
+    static constexpr float c[20] = {1.0f, 0.9510565162951535f, 0.8090169943749475f, 0.5877852522924731f, 0.30901699437494745f, 0.0f, -0.30901699437494734f, -0.587785252292473f, -0.8090169943749473f, -0.9510565162951535f, -1.0f, -0.9510565162951538f, -0.8090169943749476f, -0.5877852522924732f, -0.30901699437494756f, 0.0f, 0.30901699437494723f, 0.5877852522924729f, 0.8090169943749473f, 0.9510565162951535f};
+    static constexpr float s[20] = {0.0f, 0.3090169943749474f, 0.5877852522924731f, 0.8090169943749475f, 0.9510565162951535f, 1.0f, 0.9510565162951536f, 0.8090169943749475f, 0.5877852522924732f, 0.3090169943749475f, 0.0f, -0.3090169943749469f, -0.587785252292473f, -0.8090169943749473f, -0.9510565162951535f, -1.0f, -0.9510565162951536f, -0.8090169943749476f, -0.5877852522924734f, -0.3090169943749476f};
+};
+template <>
+struct CompTable<22> {
+    static constexpr float c[22] = {1.0f, 0.9594929736144974f, 0.8412535328311812f, 0.6548607339452851f, 0.41541501300188644f, 0.14231483827328512f, -0.142314838273285f, -0.4154150130018863f, -0.654860733945285f, -0.8412535328311811f, -0.9594929736144974f, -1.0f, -0.9594929736144975f, -0.8412535328311812f, -0.6548607339452852f, -0.41541501300188716f, -0.14231483827328523f, 0.14231483827328487f, 0.41541501300188605f, 0.6548607339452845f, 0.8412535328311812f, 0.9594929736144974f};
+    static constexpr float s[22] = {0.0f, 0.28173255684142967f, 0.5406408174555976f, 0.7557495743542583f, 0.9096319953545183f, 0.9898214418809327f, 0.9898214418809328f, 0.9096319953545184f, 0.7557495743542583f, 0.5406408174555978f, 0.28173255684142967f, 0.0f, -0.2817325568414294f, -0.5406408174555976f, -0.7557495743542582f, -0.909631995354518f, -0.9898214418809327f, -0.9898214418809328f, -0.9096319953545186f, -0.7557495743542587f, -0.5406408174555974f, -0.2817325568414298f};
+};
+template <>
+struct CompTable<24> {
+    static constexpr float c[24] = {1.0f, 0.9659258262890683f, 0.8660254037844387f, 0.7071067811865476f, 0.5000000000000001f, 0.25881904510252074f, 0.0f, -0.25881904510252063f, -0.4999999999999998f, -0.7071067811865475f, -0.8660254037844387f, -0.9659258262890682f, -1.0f, -0.9659258262890683f, -0.8660254037844388f, -0.7071067811865479f, -0.5000000000000004f, -0.25881904510252063f, 0.0f, 0.2588190451025203f, 0.5000000000000001f, 0.7071067811865474f, 0.8660254037844384f, 0.9659258262890681f};
+    static constexpr float s[24] = {0.0f, 0.25881904510252074f, 0.49999999999999994f, 0.7071067811865475f, 0.8660254037844386f, 0.9659258262890683f, 1.0f, 0.9659258262890683f, 0.8660254037844387f, 0.7071067811865476f, 0.49999999999999994f, 0.258819045102521f, 0.0f, -0.2588190451025208f, -0.4999999999999997f, -0.7071067811865471f, -0.8660254037844384f, -0.9659258262890683f, -1.0f, -0.9659258262890684f, -0.8660254037844386f, -0.7071067811865477f, -0.5000000000000004f, -0.25881904510252157f};
+};
+template <>
+struct CompTable<26> {
+    static constexpr float c[26] = {1.0f, 0.970941817426052f, 0.8854560256532099f, 0.7485107481711011f, 0.5680647467311559f, 0.35460488704253557f, 0.120536680255323f, -0.12053668025532288f, -0.35460488704253545f, -0.5680647467311557f, -0.7485107481711012f, -0.8854560256532096f, -0.970941817426052f, -1.0f, -0.9709418174260521f, -0.8854560256532101f, -0.7485107481711013f, -0.5680647467311559f, -0.3546048870425359f, -0.12053668025532357f, 0.1205366802553232f, 0.35460488704253557f, 0.5680647467311548f, 0.7485107481711007f, 0.88545602565321f, 0.970941817426052f};
+    static constexpr float s[26] = {0.0f, 0.23931566428755774f, 0.4647231720437685f, 0.6631226582407952f, 0.8229838658936564f, 0.9350162426854148f, 0.992708874098054f, 0.992708874098054f, 0.9350162426854148f, 0.8229838658936565f, 0.6631226582407952f, 0.46472317204376906f, 0.23931566428755768f, 0.0f, -0.23931566428755743f, -0.46472317204376806f, -0.663122658240795f, -0.8229838658936564f, -0.9350162426854147f, -0.992708874098054f, -0.992708874098054f, -0.9350162426854148f, -0.822983865893657f, -0.6631226582407955f, -0.4647231720437684f, -0.2393156642875578f};
+};
+template <>
+struct CompTable<28> {
+    static constexpr float c[28] = {1.0f, 0.9749279121818236f, 0.9009688679024191f, 0.7818314824680298f, 0.6234898018587336f, 0.4338837391175582f, 0.22252093395631445f, 0.0f, -0.22252093395631434f, -0.43388373911755806f, -0.6234898018587335f, -0.7818314824680295f, -0.900968867902419f, -0.9749279121818237f, -1.0f, -0.9749279121818237f, -0.9009688679024191f, -0.7818314824680296f, -0.6234898018587337f, -0.4338837391175583f, -0.2225209339563146f, 0.0f, 0.22252093395631334f, 0.43388373911755795f, 0.6234898018587334f, 0.7818314824680297f, 0.9009688679024194f, 0.9749279121818235f};
+    static constexpr float s[28] = {0.0f, 0.2225209339563144f, 0.4338837391175581f, 0.6234898018587335f, 0.7818314824680298f, 0.9009688679024191f, 0.9749279121818236f, 1.0f, 0.9749279121818236f, 0.9009688679024191f, 0.7818314824680299f, 0.6234898018587339f, 0.43388373911755823f, 0.2225209339563141f, 0.0f, -0.22252093395631384f, -0.433883739117558f, -0.6234898018587338f, -0.7818314824680297f, -0.900968867902419f, -0.9749279121818236f, -1.0f, -0.9749279121818238f, -0.9009688679024193f, -0.7818314824680299f, -0.6234898018587337f, -0.4338837391175575f, -0.22252093395631464f};
+};
+template <>
+struct CompTable<30> {
+    static constexpr float c[30] = {1.0f, 0.9781476007338057f, 0.9135454576426009f, 0.8090169943749475f, 0.6691306063588582f, 0.5000000000000001f, 0.30901699437494745f, 0.10452846326765346f, -0.10452846326765333f, -0.30901699437494734f, -0.4999999999999998f, -0.6691306063588579f, -0.8090169943749473f, -0.913545457642601f, -0.9781476007338057f, -1.0f, -0.9781476007338057f, -0.9135454576426009f, -0.8090169943749476f, -0.6691306063588585f, -0.5000000000000004f, -0.30901699437494756f, -0.10452846326765423f, 0.10452846326765299f, 0.30901699437494723f, 0.5000000000000001f, 0.6691306063588585f, 0.8090169943749473f, 0.913545457642601f, 0.9781476007338057f};
+    static constexpr float s[30] = {0.0f, 0.20791169081775931f, 0.40673664307580015f, 0.5877852522924731f, 0.7431448254773941f, 0.8660254037844386f, 0.9510565162951535f, 0.9945218953682733f, 0.9945218953682734f, 0.9510565162951536f, 0.8660254037844387f, 0.7431448254773945f, 0.5877852522924732f, 0.40673664307580004f, 0.20791169081775931f, 0.0f, -0.20791169081775907f, -0.4067366430758002f, -0.587785252292473f, -0.743144825477394f, -0.8660254037844384f, -0.9510565162951535f, -0.9945218953682733f, -0.9945218953682734f, -0.9510565162951536f, -0.8660254037844386f, -0.743144825477394f, -0.5877852522924734f, -0.40673664307580015f, -0.20791169081775898f};
+};
+template <>
+struct CompTable<32> {
+    static constexpr float c[32] = {1.0f, 0.9807852804032304f, 0.9238795325112867f, 0.8314696123025452f, 0.7071067811865476f, 0.5555702330196023f, 0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.1950903220161282f, -0.3826834323650897f, -0.555570233019602f, -0.7071067811865475f, -0.8314696123025453f, -0.9238795325112867f, -0.9807852804032304f, -1.0f, -0.9807852804032304f, -0.9238795325112868f, -0.8314696123025455f, -0.7071067811865477f, -0.5555702330196022f, -0.38268343236509034f, -0.19509032201612866f, 0.0f, 0.1950903220161283f, 0.38268343236509f, 0.5555702330196018f, 0.7071067811865474f, 0.8314696123025452f, 0.9238795325112865f, 0.9807852804032303f};
+    static constexpr float s[32] = {0.0f, 0.19509032201612825f, 0.3826834323650898f, 0.5555702330196022f, 0.7071067811865475f, 0.8314696123025452f, 0.9238795325112867f, 0.9807852804032304f, 1.0f, 0.9807852804032304f, 0.9238795325112867f, 0.8314696123025455f, 0.7071067811865476f, 0.5555702330196022f, 0.3826834323650899f, 0.1950903220161286f, 0.0f, -0.19509032201612836f, -0.38268343236508967f, -0.555570233019602f, -0.7071067811865475f, -0.8314696123025452f, -0.9238795325112865f, -0.9807852804032303f, -1.0f, -0.9807852804032304f, -0.9238795325112866f, -0.8314696123025455f, -0.7071067811865477f, -0.5555702330196022f, -0.3826834323650904f, -0.19509032201612872f};
+};
 
 // a * exp(SIGN * 2 pi i m / R), m known at compile time
 template <int R, int SIGN, int M>
@@ -226,7 +266,8 @@ __device__ __forceinline__ float2 mul_wr(float2 a) {
 template <int R, int SIGN>
 __device__ __forceinline__ void dft_small(float2 *v);
 
-// R = R1 x R2 points (6 = 2 x 3, 9 = 3 x 3, 10 = 2 x 5, 12 = 4 x 3, 14 = 2 x 7, 15 = 3 x 5), natural order in and out:
+// R = R1 x R2 points (6 = 2 x 3, 9 = 3 x 3, 10 = 2 x 5, 12 = 4 x 3, 14 = 2 x 7, 15 = 3 x 5; 18 = 2 x 9, 20 = 4 x 5, 22 = 2 x 11,
+// 24 = 4 x 6, 26 = 2 x 13, 28 = 4 x 7, 30 = 2 x 15, 32 = 4 x 8), natural order in and out:
 // n = R2 n1 + n2, k = k1 + R1 k2; R2 transforms of length R1, the twiddles w_R^(n2 k1), R1 transforms of length R2.
 template <int R, int R1, int SIGN, int N2, int K1>
 __device__ __forceinline__ void comp_twiddle(float2 *y) {
@@ -263,7 +304,9 @@ __device__ __forceinline__ void dft_comp(float2 *v) {
         for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
     }
 }
-constexpr bool is_comp_radix(int R) { return R == 6 || R == 9 || R == 10 || R == 12 || R == 14 || R == 15; }
+constexpr bool is_comp_radix(int R) {
+    return R == 6 || R == 9 || R == 10 || R == 12 || R == 14 || R == 15 || (R >= 18 && R <= 32 && R % 2 == 0);
+}
 
 template <int R, int SIGN>
 __device__ __forceinline__ void dft_small(float2 *v) {

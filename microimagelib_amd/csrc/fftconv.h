@@ -69,6 +69,14 @@ public:
     void y_part(float2 *S, int part, hipStream_t s) const;
     // S (y head done) <- y tail, z, * otf, z^-1, y tail^-1
     void yz_conv(float2 *S, const float2 *otf, hipStream_t s) const;
+    // OTF tiling.  z_forward_to_otf writes [ky][column group][kz][columns of a group]; the groups are 16 columns wide (what
+    // z_conv reads) unless the plan is told that its OTFs feed yz_conv: then a group is as wide as a yz workgroup's tile (8 or
+    // 4 columns, 16 for the smallest boxes), so that the workgroup's OTF block is contiguous instead of a half or a quarter of
+    // every 128-byte line -- which also lets the loads carry the stream hint without losing the other workgroups' share of the
+    // line in L2.  Set before the first OTF is generated; z_conv refuses the narrow tiling, yz_conv the wide one.
+    void set_yz_otf_layout(bool on);
+    bool yz_otf_layout() const { return yz_otf_; }
+    int otf_cols() const { return otf_cols_; }
     // S (y head done) <- y head^-1, x^-1, ratio / update, x, y head     (mode: kXRatio, kXUpdate, kXUpdateLast)
     void xy_pass(XMode mode, float2 *S, float *E, const float *M, float eps, hipStream_t s) const;
 
@@ -85,6 +93,8 @@ private:
     void init_two_pass();
     bool two_pass_ = false;
     bool stream_ = false;  // fft2p.hip: non-temporal hints on OTF / image / estimate accesses (large boxes)
+    bool yz_otf_ = false;  // OTFs tiled for yz_conv (otf_cols_ columns per group) instead of z_conv (16)
+    int otf_cols_ = 16;
     bool xy_any_ = false, yz_any_ = false;  // the box runs the run-time-geometry kernels of fft2p_any_xy.hip / fft2p_any_yz.hip
     DeviceBuffer<unsigned short> pairs_;  // two-pass path: pairs of 8-row blocks holding ky and -ky
     int n_pairs_ = 0;
