@@ -127,7 +127,7 @@ int mil_decon_create_backend(mil_decon **out, int nx, int ny, int nz, void *stre
 void mil_decon_destroy(mil_decon *e);
 int mil_decon_backend(const mil_decon *e);
 /* Fused backend: which kernel sequence a half view update runs (csrc/fft2p.hip): 0 = y | z-conv | y^-1 | x (four
- * passes over the spectrum), 3 = yz-conv | xy (two passes; 512 x 512 x {256, 128, 64} boxes), 1 / 2 = mixed forms kept for tests.
+ * passes over the spectrum), 3 = yz-conv | xy (two passes; nx, ny multiples of 64 from 192 / 128, nz a multiple of 64 with (ny / 64) x nz <= 4096), 1 / 2 = mixed forms kept for tests.
  * Chosen at creation: MIL_FX_TWOPASS if set, else 3 where the box allows it. */
 int mil_decon_two_pass(const mil_decon *e);
 size_t mil_decon_real_count(const mil_decon *e);

@@ -105,7 +105,7 @@ private:
     bool own_stream_ = false;
     Fft3D *fft_ = nullptr;          // rocFFT backend
     fx::ConvPlan *plan_ = nullptr;  // fused backend
-    int two_pass_ = 0;              // fused backend, 512 x 512 x {256, 128, 64} boxes: bit 0 yz kernel, bit 1 xy kernel (csrc/fft2p.hip)
+    int two_pass_ = 0;              // fused backend, boxes of ConvPlan::two_pass_supported: bit 0 yz kernel, bit 1 xy kernel (csrc/fft2p*.hip)
     static constexpr int kTwoPassDefault = 3;
     void run_fused(float *E, const float *const *M, const float2 *const *otf, const float2 *const *otf_bp, int views,
                    int iters);

@@ -21,11 +21,11 @@
 //                             fft2p_any_xy.hip: every nx = 192 .. 1024 and ny = 128 .. 1024 in multiples of 64 (the sizes
 //                             snapTransformSize produces, reference src/api_subfunc.cu:57-87), ny a run-time argument
 //   yz_conv_kernel            this file: ny = 512, nz = 256 -- register tiles of 8 rows x 8 columns x all z, two workgroups per CU
-//   yz_lds_kernel<NY, NZ>     fft2p_any_yz.hip: the tile of T rows x 4 / 8 / 16 columns x all z FITS the LDS (T x nz <= 2048) and
+//   yz_lds_kernel<NY, NZ>     fft2p_any_yz.hip: the tile of T rows x 2 / 4 / 8 / 16 columns x all z FITS the LDS (T x nz <= 4096) and
 //                             the same sequence runs on the classic LDS stage code; any nx
 // The narrow tiles are dealt so that the pieces of a 128-byte row segment land on the same XCD.
-// => nx = 192 .. 1024, ny = 128 .. 1024, nz = 64 .. 1024 in multiples of 64 with (ny / 64) x nz <= 2048, plus ... x 512 x 256 for
-// nx = 256, 512, 1024.  Larger yz tiles (384 x 384 x 384, 512 x 512 x 512 ...) keep the classic sequence.
+// => nx = 192 .. 1024, ny = 128 .. 1024, nz = 64 .. 1024 in multiples of 64 with (ny / 64) x nz <= 4096, ... x 512 x 256 on register tiles for
+// nx = 256, 512, 1024.  Larger yz tiles (ny x nz = 1024 x 512, 1024 x 1024 ...) keep the classic sequence.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "fft2p.hip is written for gfx950 (v_permlane32_swap, 160 KB of LDS per workgroup): build with --offload-arch=gfx950"
 #endif
@@ -59,14 +59,13 @@ bool static_yz(Dims b) { return static_xy(b) && b.ny == kNY && b.nz == kNZ; }
 any::Box any_box(Dims b, int xs, int pitch) { return any::Box{(int)b.nx, (int)b.ny, (int)b.nz, xs, pitch}; }
 }  // namespace
 
-// nx = 192 .. 1024 and ny = 128 .. 1024 in multiples of 64; nz a multiple of 64 with (ny / 64) x nz <= 2048 -- the yz tile of
-// ny / 64 rows x 8 columns x nz must fit the LDS (4-column tiles, 32-byte row segments, were measured SLOWER than the classic
-// sequence: 1024 x 1024 x 256, 172 against 201 it/s, profiles/r03/bench_box_ny1024.txt) -- or 512 x 256 (register yz kernel,
-// nx a power of two).  Powers of two run this file's instantiations, everything else those of fft2p_any_*.hip.
+// nx = 192 .. 1024 and ny = 128 .. 1024 in multiples of 64; nz a multiple of 64 with (ny / 64) x nz <= 4096 -- the yz tile of
+// ny / 64 rows x 2 columns x nz must fit the LDS twice over -- or 512 x 256 (register yz kernel, nx a power of two).  Powers of
+// two in x and y run this file's xy instantiations, everything else those of fft2p_any_*.hip.
 bool ConvPlan::two_pass_supported(Dims b) {
     if (b.nx % 64 || b.nx < 192 || b.nx > 1024 || b.ny % 64 || b.ny < 128 || b.ny > 1024) return false;
     if (static_yz(b)) return true;
-    return b.nz % 64 == 0 && b.nz >= 64 && b.nz <= 1024 && (b.ny / 64) * b.nz <= 2048;
+    return any::yz_covers(any::Box{(int)b.nx, (int)b.ny, (int)b.nz, (int)b.nx / 2, (int)b.nx / 2 + kW});
 }
 
 void ConvPlan::set_yz_otf_layout(bool on) {

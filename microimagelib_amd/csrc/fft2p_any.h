@@ -22,7 +22,7 @@ void xy_fill_tables(const float2 *tw_y_dev, int ny);  // this translation unit's
 void xy_pass(const Box &b, int mode, float2 *S, float *E, const float *M, const float2 *tw_x, float eps, bool stream,
              hipStream_t s);
 
-// ---- fft2p_any_yz.hip: y tail . z . OTF . z^-1 . y tail^-1 on LDS tiles for (ny / 64) x nz <= 2048, nz a multiple of 64;
+// ---- fft2p_any_yz.hip: y tail . z . OTF . z^-1 . y tail^-1 on LDS tiles for (ny / 64) x nz <= 4096, nz a multiple of 64;
 // the partial classic y passes (head / tail) for the 64 k extents
 bool yz_covers(const Box &b);
 int yz_cols(const Box &b);  // columns of a workgroup's tile = width of the OTF's column groups yz_conv expects

@@ -1,5 +1,5 @@
-// Two-pass path: the LDS-resident yz kernel for every (ny, nz) whose tile of T = ny / 64 rows x 4 .. 16 columns x nz fits the LDS
-// (T x nz <= 2048; ny = 128 .. 1024, nz = 64 .. 1024, multiples of 64), any nx -- the powers of two included: fft2p.hip keeps
+// Two-pass path: the LDS-resident yz kernel for every (ny, nz) whose tile of T = ny / 64 rows x 2 .. 16 columns x nz fits the LDS
+// (T x nz <= 4096; ny = 128 .. 1024, nz = 64 .. 1024, multiples of 64), any nx -- the powers of two included: fft2p.hip keeps
 // only the register kernel of 512 x 256 --; and the partial classic y passes for the
 // 64 k extents (see fft2p_any.h).  yz_lds_kernel<NY, NZ, 0, COLS, PAIR> of fft2p_dev.h: the row geometry (pitch, 16-column
 // groups) is a run-time argument, one instantiation per (ny, nz).
@@ -22,7 +22,10 @@ namespace {
 
 #include "fft2p_dev.h"
 
-constexpr int kMaxTile = 2048;  // T x nz: 8 columns x 2048 complex = 128 KB of LDS
+#ifndef MIL_YZ_MAX_TILE
+#define MIL_YZ_MAX_TILE 4096
+#endif
+constexpr int kMaxTile = MIL_YZ_MAX_TILE;  // T x nz: 2 columns x 4096 complex = 64 KB of LDS
 
 // Columns per tile, by the size of one column's share T x nz (complex values; profiles/r05/twopass_any_variants.txt):
 //   < 512   16 columns: whole 128-byte row segments, the workgroup still has enough work
@@ -30,7 +33,11 @@ constexpr int kMaxTile = 2048;  // T x nz: 8 columns x 2048 complex = 128 KB of 
 //            on one XCD
 //   else     4 columns, four workgroups paired: 8 columns would leave ONE workgroup per CU (no overlap of its load /
 //            transform / store phases): 384 x 256, 165 us with 8 columns, 132 us with 4
-constexpr int cols_for(int t, int nz) { return t * nz < 512 ? 16 : 2 * yz_lds_bytes(t, nz, 8) <= 163840 ? 8 : 4; }
+//   else     2 columns (T x nz beyond ~2400), eight workgroups paired: 16-byte row segments, and still 1.1 - 1.4 x the classic
+//            sequence (384 x 384 x 384: 1049 -> 1456 it/s; 512 x 512 x 512: 482 -> 514)
+constexpr int cols_for(int t, int nz) {
+    return t * nz < 512 ? 16 : 2 * yz_lds_bytes(t, nz, 8) <= 163840 ? 8 : 2 * yz_lds_bytes(t, nz, 4) <= 163840 ? 4 : 2;
+}
 // The OTF block is requested before the forward transform where the registers for it do not cost a workgroup per CU (the
 // largest tiles: two workgroups per CU either way; 512 x 256: 178 -> 169 us; 384 x 256, three workgroups: 126 -> 133 us)
 constexpr bool pref_for(int t, int nz) { return t * nz > 1706; }

@@ -506,7 +506,7 @@ template <int NY, int NZ, int NH, int COLS, bool XCDPAIR = false, bool PREF = fa
 __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
     constexpr int T = NY / 64;
     // COLS columns per tile: 16 (128-byte row segments) wherever T x NZ x 16 complex fit the LDS, else 8 or 4
-    static_assert(T * NZ * COLS <= 16384 && (COLS == 16 || COLS == 8 || COLS == 4), "yz_lds_kernel: tile does not fit the LDS");
+    static_assert(T * NZ * COLS <= 16384 && (COLS == 16 || COLS == 8 || COLS == 4 || COLS == 2), "yz_lds_kernel: tile does not fit the LDS");
     const int kPitch = yz_pitch<NH>(a), kGroups = yz_groups<NH>(a);
     constexpr int W = T * COLS, WP = W + 1;  // row r, column c of the block sit at "column" r * COLS + c
     constexpr int QR = COLS / 2;             // float4 pieces per row segment

@@ -58,7 +58,7 @@ public:
     // test aid: private OTF order -> natural [nz][ny][nx/2+1] (rocFFT / numpy rfftn order)
     void otf_to_natural(float2 *natural, const float2 *otf, hipStream_t s) const;
 
-    // ---- two-pass path (csrc/fft2p.hip, fft2p_any_*.hip; nx, ny multiples of 64 from 192 / 128, (ny / 64) x nz <= 2048): the
+    // ---- two-pass path (csrc/fft2p.hip, fft2p_any_*.hip; nx, ny multiples of 64 from 192 / 128, (ny / 64) x nz <= 4096): the
     // tail of the y transform (its stages of length ny / 64) rides in the z kernel and its first two radix-8 stages in the x
     // kernel, so a half view update is  yz_conv | xy_pass  instead of  y | z_conv | y^-1 | x_pass.  Same spectrum positions
     // and OTFs as the classic kernels.

@@ -133,13 +133,14 @@ TWO_PASS_BOXES = [(nz, ny, nx) for nx in (512, 256, 1024) for (nz, ny) in _YZ]  
 # Boxes of csrc/fft2p_any_*.hip (the 64 k extents snapTransformSize produces, reference src/api_subfunc.cu:57-87): every
 # nx = 192 .. 1024 (x transforms of 16 x 6 .. 16 x 32, half waves idle for nx / 2 = 96, 160, 224 ...), every y tail
 # T = ny / 64 = 2 .. 16 (one- and two-stage tails), every nz = 64 .. 1024 in multiples of 64 (radices 3 .. 13 in z), 16- and
-# 8-column yz tiles up to T x nz = 2048, powers of two mixed with the others.
+# 8-, 4- and 2-column yz tiles up to T x nz = 4096, powers of two mixed with the others.
 ANY_BOXES = [(256, 384, 384), (128, 320, 448),            # the two boxes of the round-4 review
              (64, 192, 192), (192, 192, 320), (64, 448, 576), (128, 576, 640), (192, 640, 704), (128, 704, 768),
              (64, 768, 832), (128, 832, 896), (64, 896, 960), (64, 960, 1024),
              (320, 384, 256), (384, 320, 512), (512, 256, 512), (1024, 128, 256), (256, 512, 384), (128, 1024, 320),
              (448, 256, 192), (640, 192, 384), (576, 128, 448),
-             (704, 128, 192), (768, 128, 192), (832, 128, 192), (896, 128, 192), (960, 128, 192)]
+             (704, 128, 192), (768, 128, 192), (832, 128, 192), (896, 128, 192), (960, 128, 192),
+             (384, 384, 384), (256, 576, 320), (256, 1024, 256), (512, 512, 192), (320, 640, 256)]  # 2-column yz tiles
 
 
 @pytest.mark.parametrize("shape", TWO_PASS_BOXES + ANY_BOXES, ids=lambda s: "x".join(str(v) for v in s[::-1]))
