@@ -325,7 +325,8 @@ def auxiliary_kernels(torch, mdev, eng, img, psf):
               (round((nx * nx + nz * nz) ** 0.5), ny, round((nx * nx + nz * nz) ** 0.5))
         per_angle = R + 4 * box[0] * box[1]
         sec = timed(torch, lambda: mdev.mip3d(img, axis, 36), reps=2)
-        out[f"mip3d_axis{axis}_36_angles"] = row("resample_mip_kernel<64 | 8 | 1, true> (x36)", sec, 36 * per_angle,
+        kern = "mip_rot_x_kernel (x36)" if axis == 1 else "transpose_xy + mip_rot_x_kernel on the transposed volume + transpose_xy of the plane (x36)"
+        out[f"mip3d_axis{axis}_36_angles"] = row(kern, sec, 36 * per_angle,
                                                  f"rotated box {box[0]}x{box[1]}x{box[2]}, resample + z projection fused; "
                                                  f"{36 * 8 * box[0] * box[1] * box[2] / 1e9:.1f} GB of box traffic avoided")
     for d, name in ((1, "xy"), (3, "yz"), (2, "zx")):

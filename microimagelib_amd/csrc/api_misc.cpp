@@ -135,12 +135,23 @@ void mip_series(float *h_out, float *d_out, const float *d_img, Dims img, Dims r
     const char *e = getenv("MIL_MIP3D_FUSED");
     const bool fused = !(e && e[0] == '0');
     DeviceBuffer<float> d_rot(fused ? 0 : (size_t)rot_box.count()), d_proj(d_out ? 0 : plane);
+    // rotations about y: the wave-uniform kernel on the transposed volume (k::mip_about_y_by_transpose); one transpose per series
+    const Dims img_t{img.ny, img.nx, img.nz}, box_t{rot_box.ny, rot_box.nx, rot_box.nz};
+    DeviceBuffer<float> d_img_t, d_plane_t;
     for (long long i = 0; i < project_num; ++i) {
         const float angle = project_step * (float)(int)i;
-        k::Affine12 m;
+        k::Affine12 m, mt;
         rot2matrix(m.m, angle, img.nx, img.ny, img.nz, axis);
         float *proj = d_out ? d_out + plane * (size_t)i : d_proj.get();
-        if (fused) {
+        if (fused && axis == 2 && k::mip_about_y_by_transpose(m, rot_box, img, mt)) {
+            if (!d_img_t.get()) {
+                d_img_t.alloc((size_t)img.count());
+                d_plane_t.alloc(plane);
+                k::transpose_xy(d_img_t.get(), d_img, img, s);
+            }
+            k::resample_mip_z(d_plane_t.get(), d_img_t.get(), box_t, img_t, mt, s);
+            k::transpose_xy(proj, d_plane_t.get(), Dims{box_t.nx, box_t.ny, 1}, s);
+        } else if (fused) {
             k::resample_mip_z(proj, d_img, rot_box, img, m, s);
         } else {
             k::affine_resample(d_rot.get(), d_img, rot_box, img, m, s);

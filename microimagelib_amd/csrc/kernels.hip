@@ -373,6 +373,25 @@ __global__ void flip_kernel(float *__restrict__ out, const float *__restrict__ i
 // For one y this is a transpose of the (x, z) plane (with one axis mirrored): a 64 x 64 tile goes through LDS so that both
 // the reads (consecutive i) and the writes (consecutive k) are whole 256-byte rows.  (Output-driven with strided reads, as
 // the reference does it, this took 1.14 ms at 512 x 512 x 256 -- 0.06 of the HBM rate; tiled: see DESIGN.md.)
+// out[z][x][y] = in[z][y][x]: 64 x 64 tiles through LDS (row pitch 65: conflict-free on both sides), 256-byte rows in and out
+__global__ __launch_bounds__(256) void transpose_xy_kernel(float *__restrict__ out, const float *__restrict__ in, int nx, int ny) {
+    __shared__ float tile[64 * 65];
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    const size_t plane = (size_t)nx * ny * blockIdx.z;
+#pragma unroll 4
+    for (int r = ly; r < 64; r += 4) {
+        const int x = x0 + lx, y = y0 + r;
+        if (x < nx && y < ny) tile[r * 65 + lx] = in[plane + (size_t)y * nx + x];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ly; r < 64; r += 4) {
+        const int y = y0 + lx, x = x0 + r;
+        if (x < nx && y < ny) out[plane + (size_t)x * ny + y] = tile[lx * 65 + r];
+    }
+}
+
 __global__ __launch_bounds__(256) void rot_y90_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g,
                                                      int direction) {
     // g.f* = output dims (fx = in.sz, fy = in.sy, fz = in.sx); g.s* = input dims
@@ -688,6 +707,14 @@ void flip3(float *out, const float *in, Dims d, hipStream_t s) {
     dim3 grid, block;
     geo_launch_dims(g, grid, block);
     hipLaunchKernelGGL(flip_kernel, grid, block, 0, s, out, in, g);
+    MIL_HIP(hipGetLastError());
+}
+
+void transpose_xy(float *out, const float *in, Dims d, hipStream_t s) {
+    if (d.count() == 0) return;
+    const dim3 grid((unsigned)((d.nx + 63) / 64), (unsigned)((d.ny + 63) / 64), (unsigned)d.nz);
+    if (d.nz > 65535 || grid.y > 65535) throw Error(-1, "transpose_xy: volume exceeds launch limits");
+    hipLaunchKernelGGL(transpose_xy_kernel, grid, dim3(256), 0, s, out, in, (int)d.nx, (int)d.ny);
     MIL_HIP(hipGetLastError());
 }
 

@@ -634,5 +634,24 @@ void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims sd, cons
     MIL_HIP(hipGetLastError());
 }
 
+// Rotation about y (mip3dgpu, rAxis 2) as a rotation about x of the TRANSPOSED volume.  rot2matrix leaves y alone -- row 1
+// is (0, 1, 0, k) -- and rows 0 and 2 do not look at y (m1 = m9 = 0): the x / z taps of a sample are the same for every y, but
+// y is the strided axis, so a wave cannot run along it.  With x and y exchanged (one transpose of the volume per SERIES, 0.2 ms)
+// the same sample is  Z.w0 (X.w0 a + X.w1 b) + Z.w1 (...)  with 64 consecutive y in the lanes and wave-uniform taps: exactly
+// mip_rot_x_kernel's walk with the matrix rows permuted -- new row 0 = (1, 0, 0, k), new row 1 = (0, m0, m2, m3), new row 2 =
+// (0, m8, m10, m11) -- the same float operations in the same order, the plane comes out transposed.  36 angles at 512 x 512 x 256:
+// 7.1 ms with resample_mip2_kernel<., 2> (one row per wave, bound by the latency of its two gathers per sample) -> see
+// profiles/r05/resample_ab.txt.  (A kernel that kept 16 rows per lane to share the taps was measured first: 10.6 ms -- sixteen
+// times the footprint per wave; not kept.)
+bool mip_about_y_by_transpose(const Affine12 &m, Dims box, Dims sd, Affine12 &mt) {
+    static const bool off = getenv("MIL_MIP3D_ROTY") && getenv("MIL_MIP3D_ROTY")[0] == '0';
+    if (off || !resample_mip2_eligible(box, sd)) return false;
+    if (!passes_through(m.m, 1, box.ny, sd.ny) || m.m[1] != 0.0f || m.m[9] != 0.0f) return false;
+    if (passes_through(m.m, 0, box.nx, sd.nx) && m.m[4] == 0.0f && m.m[8] == 0.0f) return false;  // already a rotation about x
+    const float r[12] = {1.0f, 0.0f, 0.0f, m.m[7], 0.0f, m.m[0], m.m[2], m.m[3], 0.0f, m.m[8], m.m[10], m.m[11]};
+    for (int i = 0; i < 12; ++i) mt.m[i] = r[i];
+    return true;
+}
+
 }  // namespace k
 }  // namespace mil
