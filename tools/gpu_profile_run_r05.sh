@@ -43,5 +43,7 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/reg_gap -- pyth
 find $out -size +20M -delete
 python tools/reg_profile_summary.py $out $out/summary > $out/reg_summary.log 2>&1
 python tools/reg_gap_summary.py $out/reg_gap $out/reg_gap.log > $out/reg_host_gap.txt 2>&1
-timeout 900 python tools/bench_sizes.py > $out/bench_sizes.log 2>&1; cp gpurun_out/bench_sizes.json $out/bench_sizes.json
+timeout 1500 python tools/bench_sizes.py > $out/bench_sizes.log 2>&1; cp gpurun_out/bench_sizes.json $out/bench_sizes.json
+( head -4 profiles/r05/resample_ab.txt; python tools/bench_resample_ab.py ) > $out/resample_ab.txt 2>&1
+python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/gpu_tests.log
 cut -c1-300 $out/bench.json; cut -c1-200 $out/bench_steps20.json; cat $out/reg_host_gap.txt | tail -5
