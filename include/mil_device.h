@@ -130,6 +130,9 @@ int mil_decon_backend(const mil_decon *e);
  * passes over the spectrum), 3 = yz-conv | xy (two passes; nx, ny multiples of 64 from 192 / 128, nz a multiple of 64 with (ny / 64) x nz <= 4096), 1 / 2 = mixed forms kept for tests.
  * Chosen at creation: MIL_FX_TWOPASS if set, else 3 where the box allows it. */
 int mil_decon_two_pass(const mil_decon *e);
+/* Host-side query (no device needed): does the fused backend have the two-pass kernels for this FFT box, and how wide are the
+ * column groups its OTFs are tiled in then (2 / 4 / 8 / 16; 16 also for every box on the classic sequence)?  Returns 1 / 0. */
+int mil_fx_two_pass_box(int nx, int ny, int nz, int *otf_cols);
 size_t mil_decon_real_count(const mil_decon *e);
 size_t mil_decon_spectrum_count(const mil_decon *e);
 /* d_out = C2R( R2C(d_in) * otf ), unnormalised: cufftExecR2C + multicomplex3Dgpu + cufftExecC2R,

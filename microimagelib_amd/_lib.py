@@ -75,6 +75,7 @@ SIGNATURES = {
     "mil_decon_destroy": (None, [C.c_void_p]),
     "mil_decon_backend": (C.c_int, [C.c_void_p]),
     "mil_decon_two_pass": (C.c_int, [C.c_void_p]),
+    "mil_fx_two_pass_box": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "mil_decon_convolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mil_decon_otf_to_natural": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mil_fft_digit_reversal": (C.c_int, [C.c_int, C.POINTER(C.c_ushort)]),

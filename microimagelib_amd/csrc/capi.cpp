@@ -230,6 +230,12 @@ int mil_decon_create_backend(mil_decon **out, int nx, int ny, int nz, void *stre
 }
 int mil_decon_backend(const mil_decon *e) { return e->engine.backend(); }
 int mil_decon_two_pass(const mil_decon *e) { return e->engine.two_pass(); }
+int mil_fx_two_pass_box(int nx, int ny, int nz, int *otf_cols) {
+    const mil::Dims b = dims3(nx, ny, nz);
+    const bool ok = nx > 0 && ny > 0 && nz > 0 && mil::fx::ConvPlan::supported(b) && mil::fx::ConvPlan::two_pass_supported(b);
+    if (otf_cols) *otf_cols = ok ? mil::fx::ConvPlan::yz_tile_cols(b) : 16;
+    return ok ? 1 : 0;
+}
 int mil_decon_convolve(mil_decon *e, float *d_out, const float *d_in, const void *d_otf) {
     return guarded("mil_decon_convolve", [&] { e->engine.convolve(d_out, d_in, (const float2 *)d_otf); return 0; });
 }

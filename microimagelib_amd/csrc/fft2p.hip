@@ -68,10 +68,15 @@ bool ConvPlan::two_pass_supported(Dims b) {
     return any::yz_covers(any::Box{(int)b.nx, (int)b.ny, (int)b.nz, (int)b.nx / 2, (int)b.nx / 2 + kW});
 }
 
+int ConvPlan::yz_tile_cols(Dims b) {
+    if (static_yz(b)) return 8;  // the register kernel's tiles
+    return any::yz_cols(any_box(b, (int)b.nx / 2, (int)b.nx / 2 + kW));
+}
+
 void ConvPlan::set_yz_otf_layout(bool on) {
     if (on && !two_pass_) throw Error(-1, "set_yz_otf_layout: the box has no two-pass path");
     yz_otf_ = on;
-    otf_cols_ = !on ? kW : yz_any_ ? any::yz_cols(any_box(box_, xs_, pitch_)) : 8;  // 8: the register kernel's tiles
+    otf_cols_ = !on ? kW : yz_any_ ? any::yz_cols(any_box(box_, xs_, pitch_)) : 8;
 }
 
 void ConvPlan::init_two_pass() {

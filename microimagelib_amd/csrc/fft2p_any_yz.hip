@@ -33,8 +33,8 @@ constexpr int kMaxTile = MIL_YZ_MAX_TILE;  // T x nz: 2 columns x 4096 complex =
 //            on one XCD
 //   else     4 columns, four workgroups paired: 8 columns would leave ONE workgroup per CU (no overlap of its load /
 //            transform / store phases): 384 x 256, 165 us with 8 columns, 132 us with 4
-//   else     2 columns (T x nz beyond ~2400), eight workgroups paired: 16-byte row segments, and still 1.1 - 1.4 x the classic
-//            sequence (384 x 384 x 384: 1049 -> 1456 it/s; 512 x 512 x 512: 482 -> 514)
+//   else     2 columns (T x nz beyond ~2400), eight workgroups paired: 16-byte row segments, and still 1.1 - 1.3 x the classic
+//            sequence (512 x 512 x 512: 491 -> 549 it/s; 256 x 1024 x 1024: 204 -> 252)
 constexpr int cols_for(int t, int nz) {
     return t * nz < 512 ? 16 : 2 * yz_lds_bytes(t, nz, 8) <= 163840 ? 8 : 2 * yz_lds_bytes(t, nz, 4) <= 163840 ? 4 : 2;
 }

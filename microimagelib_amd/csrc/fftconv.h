@@ -63,6 +63,7 @@ public:
     // kernel, so a half view update is  yz_conv | xy_pass  instead of  y | z_conv | y^-1 | x_pass.  Same spectrum positions
     // and OTFs as the classic kernels.
     static bool two_pass_supported(Dims box);
+    static int yz_tile_cols(Dims box);  // columns of a yz workgroup's tile (= width of the OTF's column groups), two-pass boxes
     bool two_pass() const { return two_pass_; }
     // partial classic y passes: 0 forward head (stages longer than 8), 1 inverse head, 2 forward tail (the stage of
     // length 8; also refreshes the packed-column copy z_conv reads), 3 inverse tail

@@ -67,6 +67,40 @@ def test_snap_transform_size_table(lib):
         assert lib.mil_snap_transform_size(n) == want
 
 
+def test_two_pass_box_table(lib):
+    """Which FFT boxes run two passes per convolution (csrc/fft2p*.hip) and how wide their yz tiles / OTF column groups are:
+    host-side rule, no device.  x = 192 .. 1024 and y = 128 .. 1024 in multiples of 64, z a multiple of 64 with
+    (ny / 64) * nz <= 4096; 512 x 256 in (y, z) with x a power of two is the register kernel (8 columns); the LDS kernels take 16
+    columns below (ny / 64) * nz = 512, then the widest of 8 / 4 / 2 that leaves two workgroups per CU."""
+    import ctypes
+
+    def q(nx, ny, nz):
+        c = ctypes.c_int(-1)
+        ok = lib.mil_fx_two_pass_box(nx, ny, nz, ctypes.byref(c))
+        return ok, c.value
+
+    assert q(512, 512, 256) == (1, 8)                      # the benchmark box: register yz kernel
+    assert q(384, 512, 256) == (1, 4)                      # same (y, z), x not a power of two: LDS kernel, T x nz = 2048
+    assert q(384, 384, 256) == (1, 4) and q(448, 320, 128) == (1, 8)   # the boxes of the round-4 review
+    assert q(192, 192, 64) == (1, 16) and q(256, 128, 64) == (1, 16)   # small tiles: whole 128-byte row segments
+    assert q(384, 384, 384) == (1, 4) and q(512, 512, 512) == (1, 2) and q(1024, 1024, 256) == (1, 2)
+    assert q(1024, 1024, 512) == (0, 16) and q(512, 1024, 1024) == (0, 16)   # (ny / 64) * nz beyond 4096: classic sequence
+    assert q(128, 128, 64) == (0, 16) and q(512, 512, 32) == (0, 16) and q(512, 64, 64) == (0, 16)
+    assert q(200, 256, 64) == (0, 16) and q(0, 0, 0) == (0, 16)
+    n = 0
+    for nx in range(192, 1025, 64):
+        for ny in range(128, 1025, 64):
+            for nz in range(64, 1025, 64):
+                ok, cols = q(nx, ny, nz)
+                assert ok == int((ny // 64) * nz <= 4096), (nx, ny, nz)
+                if ok:
+                    n += 1
+                    t = ny // 64
+                    assert cols in (2, 4, 8, 16) and (cols == 16) == (t * nz < 512 and not (ny == 512 and nz == 256))
+                    assert t * nz * cols <= 16384  # the tile fits the LDS
+    assert n == 1764  # 14 x extents times the 126 (ny, nz) pairs with (ny / 64) * nz <= 4096
+
+
 def test_concat_and_fexists(lib, tmp_path):
     lib.concat.restype = ctypes.c_void_p
     p = lib.concat(3, ctypes.c_char_p(b"ab"), ctypes.c_char_p(b""), ctypes.c_char_p(b"cde"))
