@@ -159,7 +159,13 @@ void mip_series(float *h_out, float *d_out, const float *d_img, Dims img, Dims r
         }
         if (h_out) MIL_HIP(hipMemcpyAsync(h_out + plane * (size_t)i, proj, plane * sizeof(float), hipMemcpyDeviceToHost, s));
     }
-    MIL_HIP(hipStreamSynchronize(s));  // the scratch buffers are freed on return
+    MIL_HIP(hipStreamSynchronize(s));
+    // the scratch buffers were only ever used on `s`: hand them back without a device-wide fence (another worker thread's
+    // registration may be queued on its own stream of this device)
+    d_rot.release_after(s);
+    d_proj.release_after(s);
+    d_img_t.release_after(s);
+    d_plane_t.release_after(s);
 }
 
 // rotated box of mip3dgpu (src/apifunc.cpp:582-590): the rotation axis keeps its extent, the other two become the diagonal
