@@ -362,6 +362,53 @@ def test_full_size_vs_oracle_fixture(dev, backend):
     eng.close()
 
 
+class _Prefixed:
+    """fixture keys of one box: b{i}_sv_samples -> sv_samples"""
+
+    def __init__(self, g, prefix):
+        self.g, self.prefix = g, prefix
+
+    def __getitem__(self, key):
+        return self.g[self.prefix + key]
+
+
+@pytest.mark.parametrize("box_index", [0, 1])
+def test_snap_sized_boxes_vs_oracle_fixture(dev, box_index):
+    """Configs 2 and 3 on FFT boxes that are not powers of two -- 384 x 384 x 256 and 448 x 320 x 128 (x, y, z), what real stacks
+    snap to (snapTransformSize, src/api_subfunc.cu:57-87) -- i.e. the run-time-geometry two-pass kernels of csrc/fft2p_any_*.hip
+    (single-stage composite radices in x, y tails of 6 / 5 rows, 4- / 8-column yz tiles) at full size: 20 single-view and 20
+    dual-view iterations against the oracle's fixture (tests/golden/make_golden_fullsize.py snap), and the rocFFT backend beside it."""
+    import torch
+    from tests import fullsize_inputs as fi
+    path = os.path.join(GOLD, "fullsize_decon_snap.npz")
+    if not os.path.exists(path):
+        pytest.skip("fullsize_decon_snap.npz not generated")
+    g = np.load(path)
+    shape = tuple(int(v) for v in g["boxes"][box_index])
+    gb = _Prefixed(g, f"b{box_index}_")
+    iters = int(g["iters"])
+    for backend in (2, 1):
+        eng = dev.DeconEngine(shape, backend=backend)
+        assert eng.backend == backend
+        if backend == 2:
+            assert eng.two_pass == 3  # both two-pass kernels
+        A, B = T(fi.hash_volume(shape, 1)), T(fi.hash_volume(shape, 2))
+        pa, pb = T(fi.psf_a()), T(fi.psf_b())
+        oa, ba = eng.gen_otf(pa), eng.gen_otf(pa, flip=True)
+        E = torch.empty_like(A)
+        eng.init_single(A, E)
+        eng.run_single(E, A, oa, ba, iters)
+        eng.sync()
+        _check_fullsize(E, gb, "sv")
+        ob, bb = eng.gen_otf(pb), eng.gen_otf(pb, flip=True)
+        eng.init_dual(A, B, E)
+        eng.run_dual(E, A, B, oa, ob, ba, bb, iters)
+        eng.sync()
+        _check_fullsize(E, gb, "dv")
+        eng.close()
+        del A, B, E, oa, ba, ob, bb
+
+
 def test_full_size_bench_like_psf_vs_oracle_fixture(dev, api):
     """The same at the PSF extent bench.py times: 64 x 64 x 64, even-sized, anisotropic (tests/fullsize_inputs.py
     psf_bench_like) -- the fused backend's two-pass kernels, the rocFFT backend and decon_singleview through host pointers
