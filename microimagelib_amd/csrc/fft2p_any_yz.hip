@@ -46,7 +46,7 @@ template <int T, int NZ>
 void launch_yz(const YzArgs &a, const float2 *tw_z, int xs, hipStream_t s) {
     constexpr int COLS = cols_for(T, NZ);
     const dim3 grid((unsigned)(64 * (xs / COLS) + a.pair_blocks)), block(kYzThreads);
-    hipLaunchKernelGGL((yz_lds_kernel<64 * T, NZ, 0, COLS, (COLS < kW), pref_for(T, NZ), true>), grid, block, 0, s, a, tw_z);
+    hipLaunchKernelGGL((yz_lds_kernel<64 * T, NZ, 0, COLS, (COLS < kW), pref_for(T, NZ)>), grid, block, 0, s, a, tw_z);
 }
 
 // (T, nz = 64 J): T = 2 .. 16, J = 1 .. 16
@@ -122,7 +122,9 @@ void yz_conv(const Box &b, float2 *S, const float2 *otf, const unsigned short *n
     a.pair_blocks = n_pairs;
     a.stamps = nullptr;
     a.pitch = b.pitch; a.groups = b.xs / kW;
-    a.otf_stream = (long long)b.nx * b.ny * b.nz * 4 >= kStreamVolumeBytes;
+    // OTF loads with the stream hint from 96 MB per volume: at 64 MB the two OTFs of a view still survive in the Infinity Cache
+    // from one iteration to the next (hinted there: -1 .. -3 % on 512 x 512 x 64, 512 x 256 x 128, 256^3; +1 % from 128 MB)
+    a.otf_stream = (long long)b.nx * b.ny * b.nz * 4 >= 2 * kStreamVolumeBytes;
     if (const char *e = getenv("MIL_FX_STREAM")) a.otf_stream = e[0] == '1';
     if (!dispatch_yz(b.ny / 64, b.nz, a, tw_z, b.xs, s, std::make_integer_sequence<int, 15>{}))
         throw Error(-1, "two-pass path: no yz kernel for this (ny, nz)");

@@ -487,10 +487,13 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
 
 // ---------------------------------------------------------------------------
 // yz_conv where the tile fits the LDS: T rows (T = NY / 64, the y tail) x COLS columns x NZ z <= 16384 complex = 128 KB
-// + padding -- COLS = 16 (128-byte row segments) for T x NZ <= 1024, 8 or 4 columns for the taller boxes -- so the sequence
+// + padding -- COLS = 16 (128-byte row segments) for the smallest tiles, 8 / 4 / 2 columns for the taller ones (the host's rule:
+// fft2p_any_yz.hip) -- so the sequence
 //   y tail(T) . z . OTF . z^-1 . y tail(T)^-1
-// runs on tile[z][T rows x 16 columns] with the classic LDS stage code, T * 16 "columns" per z position.  One trip of the
-// spectrum through HBM (3 C'') where the classic kernels make three (y tail | z-conv | y tail^-1: 7 C'').
+// runs on tile[z][T rows x COLS columns] with the classic LDS stage code, T * COLS "columns" per z position.  The y tail rides
+// in the load and in the store -- the T rows of a (z, column pair) in one thread's registers -- instead of making two more
+// passes over the tile in LDS (576 x 128: 160 -> 132 us).  One trip of the spectrum through HBM (3 C'') where the classic
+// kernels make three (y tail | z-conv | y tail^-1: 7 C'').
 // ---------------------------------------------------------------------------
 // LDS of one workgroup: tile[NZ][max(T COLS, 2 T) + 1] + NZ twiddles (complex)
 constexpr int yz_lds_bytes(int t, int nz, int cols) { return (nz * ((t * cols > 2 * t ? t * cols : 2 * t) + 1) + nz) * 8; }
@@ -500,12 +503,9 @@ constexpr int yz_lds_occ() {
     constexpr int wgs = 163840 / yz_lds_bytes(NY / 64, NZ, COLS);
     return wgs >= 3 ? 6 : wgs == 2 ? 4 : 2;
 }
-// FUSE: the y tail rides in the load and in the store (the T rows of a (z, column pair) in one thread's registers) instead
-// of making two more passes over the tile in LDS.
-template <int NY, int NZ, int NH, int COLS, bool XCDPAIR = false, bool PREF = false, bool FUSE = false>
+template <int NY, int NZ, int NH, int COLS, bool XCDPAIR = false, bool PREF = false>
 __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_lds_kernel(YzArgs a, const float2 *__restrict__ tw_z) {
     constexpr int T = NY / 64;
-    // COLS columns per tile: 16 (128-byte row segments) wherever T x NZ x 16 complex fit the LDS, else 8 or 4
     static_assert(T * NZ * COLS <= 16384 && (COLS == 16 || COLS == 8 || COLS == 4 || COLS == 2), "yz_lds_kernel: tile does not fit the LDS");
     const int kPitch = yz_pitch<NH>(a), kGroups = yz_groups<NH>(a);
     constexpr int W = T * COLS, WP = W + 1;  // row r, column c of the block sit at "column" r * COLS + c
@@ -538,12 +538,10 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
     }
     float2 *base = a.S + (long long)(T * b) * kPitch + g * COLS;
     const long long zstride = (long long)NY * kPitch;
-    // ---- load: NZ x T row segments
-    constexpr int TOTAL = NZ * T * QR;  // float4 pieces
-    // FUSE: a thread takes the T rows of a column PAIR (float4 accesses), or of one column where 2 T complex values + their
-    // transform would not fit the registers of three workgroups per CU (T >= 10)
+    // ---- load + y tail: a thread takes the T rows of a column PAIR (float4 accesses), or of one column where 2 T complex values +
+    // their transform would not fit the registers of three workgroups per CU (T >= 10)
     constexpr bool kPairCols = T < 10;
-    if constexpr (FUSE && kPairCols) {
+    if constexpr (kPairCols) {
 #pragma unroll 1
         for (int i = tid; i < NZ * QR; i += kYzThreads) {
             const int q = i % QR, z = i / QR;
@@ -565,7 +563,7 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
                 p[r * COLS + 1] = c1[r];
             }
         }
-    } else if constexpr (FUSE) {
+    } else {
 #pragma unroll 1
         for (int i = tid; i < NZ * COLS; i += kYzThreads) {
             const int c = i % COLS, z = i / COLS;
@@ -577,29 +575,8 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
 #pragma unroll
             for (int r = 0; r < T; ++r) p[r * COLS] = c0[r];
         }
-    } else {
-#pragma unroll 1
-    for (int it0 = 0; it0 < TOTAL; it0 += kYzThreads * kBatch) {
-        float4 v[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kYzThreads + tid;
-            const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
-            if (idx < TOTAL) v[j] = *reinterpret_cast<const float4 *>(base + z * zstride + (long long)row * kPitch + 2 * q);
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int idx = it0 + j * kYzThreads + tid;
-            const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
-            if (idx < TOTAL) {
-                float2 *p = tile + z * WP + row * COLS + 2 * q;
-                p[0] = make_float2(v[j].x, v[j].y);
-                p[1] = make_float2(v[j].z, v[j].w);
-            }
-        }
     }
-    }
-    // ---- OTF (the classic tiling [row][16-column group][kz][16]): PREF requests the workgroup's block now, so that it arrives
+    // ---- OTF ([row][group of COLS columns][kz][COLS], ConvPlan::set_yz_otf_layout): PREF requests the workgroup's block now, so that it arrives
     // under the forward transform (PIECES / 512 float4 per thread held in registers until the product)
     constexpr int PIECES = T * NZ * QR;  // float4 pieces
     constexpr int OPER = PREF ? (PIECES + kYzThreads - 1) / kYzThreads : 1;
@@ -622,11 +599,6 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
         }
     }
     lds_barrier();
-    if constexpr (!FUSE) {
-        // ---- y tail: the transform of length T over the rows of every (z, column)
-        for (int i = tid; i < NZ * COLS; i += kYzThreads) tail_forward<T>(tile + (i / COLS) * WP + (i % COLS), COLS);
-        lds_barrier();
-    }
     fft_dif<NZ, NZ, -1, W, kYzThreads, WP>(tile, tw);
     if constexpr (PREF) {
 #pragma unroll
@@ -647,7 +619,7 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
             for (int j = 0; j < kBatch; ++j) {
                 const int idx = it0 + j * kYzThreads + tid;
                 // the stream hint only on large boxes (a.otf_stream): the OTFs of small ones survive in the Infinity Cache from one
-                // iteration to the next (hinted: -4 % at 64 MB volumes, profiles/r05/nontemporal_streams.txt)
+                // iteration to the next
                 if (idx < PIECES) v[j] = otf_piece(idx);
             }
 #pragma unroll
@@ -664,7 +636,7 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
     }
     lds_barrier();
     fft_dit<NZ, NZ, +1, W, kYzThreads>(tile, tw);
-    if constexpr (FUSE && kPairCols) {
+    if constexpr (kPairCols) {
         // ---- y tail back and store; the packed column (group 0, column 0) belongs to the pair blocks
 #pragma unroll 1
         for (int i = tid; i < NZ * QR; i += kYzThreads) {
@@ -685,8 +657,7 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
                 else *reinterpret_cast<float4 *>(dst + (long long)r * kPitch) = make_float4(c0[r].x, c0[r].y, c1[r].x, c1[r].y);
             }
         }
-        return;
-    } else if constexpr (FUSE) {
+    } else {
 #pragma unroll 1
         for (int i = tid; i < NZ * COLS; i += kYzThreads) {
             const int c = i % COLS, z = i / COLS;
@@ -700,18 +671,6 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
                 for (int r = 0; r < T; ++r) base[z * zstride + (long long)r * kPitch + c] = c0[r];
             }
         }
-        return;
-    }
-    for (int i = tid; i < NZ * COLS; i += kYzThreads) tail_inverse<T>(tile + (i / COLS) * WP + (i % COLS), COLS);
-    lds_barrier();
-    // ---- store; the packed column (group 0, column 0) belongs to the pair blocks
-#pragma unroll 4
-    for (int idx = tid; idx < TOTAL; idx += kYzThreads) {
-        const int q = idx % QR, row = (idx / QR) % T, z = idx / (T * QR);
-        const float2 *p = tile + z * WP + row * COLS + 2 * q;
-        float2 *dst = base + z * zstride + (long long)row * kPitch + 2 * q;
-        if (g == 0 && q == 0) dst[1] = p[1];
-        else *reinterpret_cast<float4 *>(dst) = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
     }
 }
 
