@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kYzThreads, (yz_lds_occ<NY, NZ, COLS>())) void yz_l
 }
 
 // ---------------------------------------------------------------------------
-// xy pass: the 64 rows y = n2 + T m (T = NY / 64) of one z plane in registers (thread = column); y head^-1, then per 16 rows
+// xy pass: the 64 rows y = n2 + T m (T = NY / 64) of one z plane in registers (thread = column); y head^-1, then per 16 (32) rows
 // x^-1 . op . x through LDS (the classic x kernel's tile), then y head
 // ---------------------------------------------------------------------------
 struct XyArgs {
@@ -710,15 +710,15 @@ __device__ __forceinline__ int xy_pos_m(int b) {
     }
 }
 
-// the LDS stages of the sub-transforms of length L (L divides M = NH / 16) on the skewed 16-row tile
-template <int NH, int NT, int L, bool DIT, int SIGN>
+// the LDS stages of the sub-transforms of length L (L divides M = NH / 16) on the skewed tile of RB rows
+template <int NH, int NT, int RB, int L, bool DIT, int SIGN>
 __device__ __forceinline__ void xy_stage_rec(float2 *tile, const float2 *tw) {
-    constexpr int M = NH / 16, RB = 16;
+    constexpr int M = NH / 16;
     if constexpr (L > 1) {
         constexpr int R = xy_radix(L);
         if constexpr (DIT) {
             if constexpr (L / R > 1) {
-                xy_stage_rec<NH, NT, L / R, true, SIGN>(tile, tw);
+                xy_stage_rec<NH, NT, RB, L / R, true, SIGN>(tile, tw);
                 lds_barrier();
             }
             fft_stage<NH, R, L, true, SIGN, RB, NT, RB + 1, M>(tile, tw);
@@ -726,16 +726,16 @@ __device__ __forceinline__ void xy_stage_rec(float2 *tile, const float2 *tw) {
             fft_stage<NH, R, L, false, SIGN, RB, NT, RB + 1, M>(tile, tw);
             if constexpr (L / R > 1) {
                 lds_barrier();
-                xy_stage_rec<NH, NT, L / R, false, SIGN>(tile, tw);
+                xy_stage_rec<NH, NT, RB, L / R, false, SIGN>(tile, tw);
             }
         }
     }
 }
 
 // the LDS stage(s) of length M = NH / 16 of the x transform
-template <int NH, int NT, bool DIT, int SIGN>
+template <int NH, int NT, int RB, bool DIT, int SIGN>
 __device__ __forceinline__ void xy_stage_m(float2 *tile, const float2 *tw) {
-    xy_stage_rec<NH, NT, NH / 16, DIT, SIGN>(tile, tw);
+    xy_stage_rec<NH, NT, RB, NH / 16, DIT, SIGN>(tile, tw);
 }
 
 // Occupancy.  The 64 rows x NH columns of a workgroup live in registers (128 per thread), which left room for two waves per
@@ -758,6 +758,13 @@ struct XyCfg {
     static constexpr int threads = (NH + 63) / 64 * 64;
     static constexpr int occ = NH > MIL_XY_OCC3_MAX ? 2 : 3;
     static constexpr int park = NH > MIL_XY_OCC3_MAX ? 0 : 8;
+    // rows per trip through the LDS.  Where a CU holds one workgroup anyway (NH > 256) two trips of 32 rows replace four of
+    // 16 -- half the barrier-separated phases (five per trip) for twice the tile: 128 x 512 x nx ratio kernel 189 -> 182 us at
+    // nx = 576, 242 -> 224 us at nx = 1024 (profiles/r05/twopass_any_variants.txt)
+#ifndef MIL_XY_RB32_FROM
+#define MIL_XY_RB32_FROM (MIL_XY_OCC3_MAX + 1)
+#endif
+    static constexpr int rb = NH >= MIL_XY_RB32_FROM ? 32 : 16;
 };
 
 // lanes l and l + 32 exchange (v_permlane32_swap):  a' = (a of the lower lanes | b of the LOWER lanes),
@@ -794,7 +801,8 @@ __global__ __launch_bounds__(XyCfg<NH>::threads, XyCfg<NH>::occ) void xy_kernel(
     const int ny = 64 * T;
     constexpr int M = NH / 16;  // length of the LDS stage of the x transform
     constexpr int kPitch = Geo<NH>::pitch;
-    constexpr int RB = 16, WP = RB + 1, NX = 2 * NH;  // 16 rows per trip through LDS: tile[position][row]
+    constexpr int RB = XyCfg<NH>::rb, WP = RB + 1, NX = 2 * NH;  // RB rows per trip through LDS: tile[position][row]
+    constexpr int PASSES = RB / 8;                           // passes of the fused stage (8 rows each)
     constexpr int PARK = XyCfg<NH>::park, NV = 64 - PARK;
     constexpr int NT = XyCfg<NH>::threads;  // NH rounded up to whole waves
     constexpr bool RAGGED = NT != NH;       // the last 32 lanes hold no column, the last 32 lane pairs no butterfly
@@ -841,10 +849,10 @@ __global__ __launch_bounds__(XyCfg<NH>::threads, XyCfg<NH>::occ) void xy_kernel(
     constexpr int SCS = 2 * M * WP + 2;
     const unsigned svoff = pair_live ? (unsigned)(srow * T * NX + 2 * si) * 4u : kDropped;
     const unsigned rsoff0 = (unsigned)((z * ny + n2) * NX) * 4u;  // + grp * 16 T rows, + pass * 8 T rows, + 4 M r floats
-    const unsigned rgrp = 16u * T * NX * 4u, spass = 8u * T * NX * 4u;
+    const unsigned rgrp = (unsigned)RB * T * NX * 4u, spass = 8u * T * NX * 4u;
     constexpr unsigned srj = 4u * M * 4u;
     float2 v[64];
-    float2 pre[16];  // M / E of the trip's two passes
+    float2 pre[16];  // M / E of the pass at hand and of the next one
     MIL_STAMP(0);
     // Hermitian fold / split.  With A = own + oth, B = own - oth (oth = the pair lane's value) both lanes of a pair evaluate
     // the SAME expressions -- no per-lane selects (they were a fifth of the kernel's arithmetic):
@@ -883,8 +891,8 @@ __global__ __launch_bounds__(XyCfg<NH>::threads, XyCfg<NH>::occ) void xy_kernel(
 #pragma unroll
     for (int i = 0; i < PARK; ++i) park[i * NT] = v[NV + i];
     lds_barrier();  // tw
-    // ---- x^-1 . op . x, sixteen rows per trip (rows m = r + 16 grp).  A real loop: the rows in flight always sit in
-    // v[0..15] and the queue moves up by one group per trip.  (Unrolled, the compiler parks half of the tile in scratch.)
+    // ---- x^-1 . op . x, RB rows per trip (rows m = r + RB grp).  A real loop: the rows in flight always sit in
+    // v[0 .. RB - 1] and the queue moves up by one group per trip.  (Unrolled, the compiler parks half of the tile in scratch.)
 #pragma unroll 1
     for (int grp = 0; grp < 64 / RB; ++grp) {
         const unsigned rsoff = rsoff0 + grp * rgrp;
@@ -910,13 +918,13 @@ __global__ __launch_bounds__(XyCfg<NH>::threads, XyCfg<NH>::occ) void xy_kernel(
         if (grp == 0) MIL_STAMP(8);
         lds_barrier();
         if (grp == 0) MIL_STAMP(9);
-        xy_stage_m<NH, NT, true, +1>(tile, tw);  // DIT stage(s) of length M
+        xy_stage_m<NH, NT, RB, true, +1>(tile, tw);  // DIT stage(s) of length M
         lds_barrier();
         if (grp == 0) MIL_STAMP(10);
         // ---- last inverse stages, real-space operation, first forward stages: radix 2 (sub-transforms of length 2 M, split
         // over the lanes l and l + 32) and radix 8 (length NH) on 8 elements per lane, two passes of 8 rows
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+        for (int ps = 0; ps < PASSES; ++ps) {
             float2 *p = sp + 8 * ps;
             float2 t[8], mm[8];
             // twiddle addresses and the radix-2 twiddle are recomputed / re-read per pass: hoisted out of the trip loop they
@@ -925,10 +933,11 @@ __global__ __launch_bounds__(XyCfg<NH>::threads, XyCfg<NH>::occ) void xy_kernel(
             asm volatile("" : "+v"(si_l), "+v"(wi_l));
             const float2 wl = tw[wi_l];  // w_2M^sbi
 #pragma unroll
-            for (int r = 0; r < 8; ++r) mm[r] = pre[8 * ps + r];
-            if (ps == 0) {  // the second pass's M / E
+            for (int r = 0; r < 8; ++r) mm[r] = pre[8 * (ps & 1) + r];
+            if (ps + 1 < PASSES) {  // the next pass's M / E
 #pragma unroll
-                for (int r = 0; r < 8; ++r) pre[8 + r] = buf_load2<Aux<STREAM>::ld_real>(rr, svoff, rsoff + spass + r * srj);
+                for (int r = 0; r < 8; ++r)
+                    pre[8 * ((ps + 1) & 1) + r] = buf_load2<Aux<STREAM>::ld_real>(rr, svoff, rsoff + (ps + 1) * spass + r * srj);
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) t[c] = p[c * SCS];
@@ -989,7 +998,7 @@ __global__ __launch_bounds__(XyCfg<NH>::threads, XyCfg<NH>::occ) void xy_kernel(
             continue;
         }
         lds_barrier();
-        xy_stage_m<NH, NT, false, -1>(tile, tw);  // DIF stage(s) of length M
+        xy_stage_m<NH, NT, RB, false, -1>(tile, tw);  // DIF stage(s) of length M
         lds_barrier();
         if (grp == 0) MIL_STAMP(12);
         // The queue moves up by one trip; then the Hermitian split back into this thread's column: each lane picks up its
