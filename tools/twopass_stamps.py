@@ -1,5 +1,6 @@
 """In-kernel phase stamps of the two-pass kernels (csrc/fft2p.hip, mil_fx_set_stamps): where a workgroup's time goes.
-Usage: MIL_FX_TWOPASS=3 python tools/twopass_stamps.py"""
+Usage: MIL_FX_TWOPASS=3 python tools/twopass_stamps.py [--shape=nz,ny,nx]   (a -DMIL_FX_STAMPS build: tools/build_variant.sh;
+stamps exist in the compile-time kernels of fft2p.hip only: nx, ny powers of two)"""
 import ctypes
 import os
 import sys
@@ -16,7 +17,11 @@ from microimagelib_amd import _lib, api  # noqa: E402
 
 lib = _lib.load()
 buf = torch.zeros(2 * 2048 * 16, dtype=torch.int64, device="cuda")
-img = fi.hash_volume(fi.FULL_SHAPE, 1)
+shape = fi.FULL_SHAPE
+for arg in sys.argv[1:]:
+    if arg.startswith("--shape="):
+        shape = tuple(int(v) for v in arg[len("--shape="):].split(","))
+img = fi.hash_volume(shape, 1)
 psf = fi.psf_a()
 api.decon_singleview(img, psf, 3, gpu_mem_mode=1)  # warm
 lib.mil_fx_set_stamps.argtypes = [ctypes.c_void_p]
@@ -28,6 +33,9 @@ st = buf.cpu().numpy().reshape(2, 2048, 16)
 for name, s, n in (("yz_conv (regular tiles)", st[0], 2048), ("xy, ratio launch", st[1], 2048)):
     s = s[:n].astype(np.int64)
     s = s[s[:, 6] > 0]  # workgroups that stamped (the packed-column blocks of yz_conv do not)
+    if s.shape[0] == 0:
+        print(name, "no stamps (this box runs a kernel without them)")
+        continue
     t0 = s[:, 0].min()
     d = np.diff(s[:, :7], axis=1) / 100.0  # us
     print(name, "kernel span %.1f us" % ((s[:, 6].max() - t0) / 100.0))
