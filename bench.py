@@ -87,7 +87,7 @@ def kernel_source_hashes():
     """sha256 of the kernel sources the PMC traffic figures depend on (profiles/pmc_traffic.json carries the same map)."""
     import hashlib
     out = {}
-    for f in ("fft.hip", "fft2p.hip", "fft2p_dev.h", "fft_dev.h", "kernels.hip"):
+    for f in ("fft.hip", "fft2p.hip", "fft2p_any_yz.hip", "fft2p_dev.h", "fft_dev.h", "kernels.hip"):
         path = os.path.join(ROOT, "microimagelib_amd", "csrc", f)
         if os.path.exists(path):
             out[f] = hashlib.sha256(open(path, "rb").read()).hexdigest()

@@ -54,8 +54,15 @@ namespace {
 bool static_xy(Dims b) {
     return (b.nx == 256 || b.nx == 512 || b.nx == 1024) && (b.ny == 1024 || b.ny == 512 || b.ny == 256 || b.ny == 128);
 }
-// ... and ny = 512, nz = 256 (the register yz kernel); every other (ny, nz) runs the LDS kernel of fft2p_any_yz.hip
-bool static_yz(Dims b) { return static_xy(b) && b.ny == kNY && b.nz == kNZ; }
+// The register yz kernel (ny = 512, nz = 256, nx a power of two) was THE yz kernel of rounds 2 - 5; at the end of round 5 the LDS
+// kernel of fft2p_any_yz.hip (4-column tiles paired on an XCD, fused y tail, OTF requested up front, per-workgroup OTF tiling)
+// overtook it on that very box -- 175 against 189 us per launch, 1 411 against 1 367 it/s at 512 x 512 x 256 -- and runs every
+// (ny, nz) now.  MIL_FX_YZ_REGISTER=1 (read when a plan is created) brings the register kernel back for comparisons.
+bool static_yz(Dims b) {
+    if (!(static_xy(b) && b.ny == kNY && b.nz == kNZ)) return false;
+    const char *e = getenv("MIL_FX_YZ_REGISTER");
+    return e && e[0] == '1';
+}
 any::Box any_box(Dims b, int xs, int pitch) { return any::Box{(int)b.nx, (int)b.ny, (int)b.nz, xs, pitch}; }
 }  // namespace
 

@@ -70,8 +70,8 @@ def test_snap_transform_size_table(lib):
 def test_two_pass_box_table(lib):
     """Which FFT boxes run two passes per convolution (csrc/fft2p*.hip) and how wide their yz tiles / OTF column groups are:
     host-side rule, no device.  x = 192 .. 1024 and y = 128 .. 1024 in multiples of 64, z a multiple of 64 with
-    (ny / 64) * nz <= 4096; 512 x 256 in (y, z) with x a power of two is the register kernel (8 columns); the LDS kernels take 16
-    columns below (ny / 64) * nz = 512, then the widest of 8 / 4 / 2 that leaves two workgroups per CU."""
+    (ny / 64) * nz <= 4096; the LDS yz kernels take 16 columns below (ny / 64) * nz = 512, then the widest of 8 / 4 / 2 that leaves
+    two workgroups per CU."""
     import ctypes
 
     def q(nx, ny, nz):
@@ -79,8 +79,8 @@ def test_two_pass_box_table(lib):
         ok = lib.mil_fx_two_pass_box(nx, ny, nz, ctypes.byref(c))
         return ok, c.value
 
-    assert q(512, 512, 256) == (1, 8)                      # the benchmark box: register yz kernel
-    assert q(384, 512, 256) == (1, 4)                      # same (y, z), x not a power of two: LDS kernel, T x nz = 2048
+    assert q(512, 512, 256) == (1, 4)                      # the benchmark box: LDS yz kernel, T x nz = 2048 (MIL_FX_YZ_REGISTER=1: 8)
+    assert q(384, 512, 256) == (1, 4)                      # same (y, z), x not a power of two
     assert q(384, 384, 256) == (1, 4) and q(448, 320, 128) == (1, 8)   # the boxes of the round-4 review
     assert q(192, 192, 64) == (1, 16) and q(256, 128, 64) == (1, 16)   # small tiles: whole 128-byte row segments
     assert q(384, 384, 384) == (1, 4) and q(512, 512, 512) == (1, 2) and q(1024, 1024, 256) == (1, 2)
@@ -96,7 +96,7 @@ def test_two_pass_box_table(lib):
                 if ok:
                     n += 1
                     t = ny // 64
-                    assert cols in (2, 4, 8, 16) and (cols == 16) == (t * nz < 512 and not (ny == 512 and nz == 256))
+                    assert cols in (2, 4, 8, 16) and (cols == 16) == (t * nz < 512)
                     assert t * nz * cols <= 16384  # the tile fits the LDS
     assert n == 1764  # 14 x extents times the 126 (ny, nz) pairs with (ny / 64) * nz <= 4096
 

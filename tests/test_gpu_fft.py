@@ -194,6 +194,45 @@ def test_two_pass_kernels_agree_with_the_classic_sequence(dev, monkeypatch, shap
             assert err < 3e-6, (mode, "single" if k == 0 else "dual", err)
 
 
+@pytest.mark.parametrize("nx", [256, 512, 1024])
+def test_register_yz_kernel_agrees_with_the_lds_kernel(dev, monkeypatch, nx):
+    """ny = 512, nz = 256 with nx a power of two has a second yz kernel: register tiles of 8 rows x 8 columns x all z
+    (csrc/fft2p.hip yz_conv_kernel, the default of rounds 2 - 5, MIL_FX_YZ_REGISTER=1 since the LDS kernel overtook it).  Same
+    positions and twiddles, OTFs tiled 8 instead of 4 columns wide: 3 single-view + 2 dual-view iterations must agree to 3e-6."""
+    import torch
+    from tests import fullsize_inputs as fi
+    shape = (256, 512, nx)
+    A, B = T(fi.hash_volume(shape, 1)), T(fi.hash_volume(shape, 2))
+    pa, pb = T(fi.psf_a()), T(fi.psf_b())
+    outs = {}
+    for reg in ("0", "1"):
+        monkeypatch.setenv("MIL_FX_YZ_REGISTER", reg)
+        eng = dev.DeconEngine(shape, backend=dev.DeconEngine.FUSED)
+        assert eng.two_pass == 3
+        oa, ba = eng.gen_otf(pa), eng.gen_otf(pa, flip=True)
+        ob, bb = eng.gen_otf(pb), eng.gen_otf(pb, flip=True)
+        a, b = A.clone(), B.clone()
+        E = torch.empty_like(a)
+        eng.init_single(a, E)
+        eng.run_single(E, a, oa, ba, 3)
+        eng.sync()
+        sv = E.clone()
+        a = A.clone()
+        eng.init_dual(a, b, E)
+        eng.run_dual(E, a, b, oa, ob, ba, bb, 2)
+        eng.sync()
+        outs[reg] = (sv, E.clone())
+        eng.close()
+        del oa, ba, ob, bb
+    monkeypatch.delenv("MIL_FX_YZ_REGISTER")
+    for k in (0, 1):
+        want, got = outs["0"][k].double(), outs["1"][k].double()
+        assert bool(torch.isfinite(got).all())
+        floor = float(want.abs().mean())
+        err = float(((got - want).abs() / torch.clamp(want.abs(), min=floor)).max())
+        assert err < 3e-6, (nx, "single" if k == 0 else "dual", err)
+
+
 def test_snap_sized_box_runs_rl_on_the_fused_backend(dev):
     """A 50x180x300 stack snaps to 64x192x320 (radices 3 and 5): fused backend, parity with the oracle."""
     import torch

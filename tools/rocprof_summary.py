@@ -21,7 +21,7 @@ OURS = {  # kernel-name pattern -> bench.py family key (config size 512x512x256)
     "fused": {r"x_kernel<256, 3,": "x_update", r"x_kernel<256, 2,": "x_ratio", r"col_kernel<512, 512, [01]>": "y_pass",
               r"col_kernel<256, 256, 2>": "z_conv",
               # two passes per convolution (csrc/fft2p.hip)
-              r"yz_conv_kernel": "yz_conv", r"xy_kernel<2(, 512, 256)?(, (true|false))?>": "xy_ratio",
+              r"yz_conv_kernel|yz_lds_kernel<512, 256,": "yz_conv", r"xy_kernel<2(, 512, 256)?(, (true|false))?>": "xy_ratio",
               r"xy_kernel<3(, 512, 256)?(, (true|false))?>": "xy_update"},
     "rocfft": {r"ew_inplace2_kernel<.*UpdateOp": "rl_update", r"ew_inplace2_kernel<.*RatioOp": "rl_ratio",
                r"cmul_kernel": "cmul_otf"},
