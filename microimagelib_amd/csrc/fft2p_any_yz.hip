@@ -36,11 +36,17 @@ constexpr int kMaxTile = MIL_YZ_MAX_TILE;  // T x nz: 2 columns x 4096 complex =
 //   else     2 columns (T x nz beyond ~2400), eight workgroups paired: 16-byte row segments, and still 1.1 - 1.3 x the classic
 //            sequence (512 x 512 x 512: 491 -> 549 it/s; 256 x 1024 x 1024: 204 -> 252)
 constexpr int cols_for(int t, int nz) {
+#ifdef MIL_YZ_FORCE_COLS_2048  // experiments: tile width at T x nz = 2048
+    if (t * nz == 2048) return MIL_YZ_FORCE_COLS_2048;
+#endif
     return t * nz < 512 ? 16 : 2 * yz_lds_bytes(t, nz, 8) <= 163840 ? 8 : 2 * yz_lds_bytes(t, nz, 4) <= 163840 ? 4 : 2;
 }
 // The OTF block is requested before the forward transform where the registers for it do not cost a workgroup per CU (the
 // largest tiles: two workgroups per CU either way; 512 x 256: 178 -> 169 us; 384 x 256, three workgroups: 126 -> 133 us)
-constexpr bool pref_for(int t, int nz) { return t * nz > 1706; }
+#ifndef MIL_YZ_PREF_FROM
+#define MIL_YZ_PREF_FROM 1706
+#endif
+constexpr bool pref_for(int t, int nz) { return t * nz > MIL_YZ_PREF_FROM; }
 
 template <int T, int NZ>
 void launch_yz(const YzArgs &a, const float2 *tw_z, int xs, hipStream_t s) {

@@ -8,7 +8,7 @@ cs=$root/microimagelib_amd/csrc; obj=$root/build/obj; out=$root/build/variants
 mkdir -p $out
 base="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-fast-math -Wall -Wno-unused-result"
 case $src in
-  fft2p.hip) fl="$base -ffp-contract=fast -fno-slp-vectorize" ;;
+  fft2p.hip|fft2p_any_xy.hip|fft2p_any_yz.hip) fl="$base -ffp-contract=fast -fno-slp-vectorize" ;;
   fft.hip) fl="$base -ffp-contract=fast" ;;
   corr_padded.hip|resample_march.hip) fl="$base -fvisibility-inlines-hidden -ffp-contract=off -fno-slp-vectorize -mllvm -disable-vector-combine" ;;
   *) fl="$base -fvisibility-inlines-hidden -ffp-contract=off" ;;
