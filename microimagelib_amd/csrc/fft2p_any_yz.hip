@@ -41,12 +41,13 @@ constexpr int cols_for(int t, int nz) {
 #endif
     return t * nz < 512 ? 16 : 2 * yz_lds_bytes(t, nz, 8) <= 163840 ? 8 : 2 * yz_lds_bytes(t, nz, 4) <= 163840 ? 4 : 2;
 }
-// The OTF block is requested before the forward transform where the registers for it do not cost a workgroup per CU (the
-// largest tiles: two workgroups per CU either way; 512 x 256: 178 -> 169 us; 384 x 256, three workgroups: 126 -> 133 us)
-#ifndef MIL_YZ_PREF_FROM
-#define MIL_YZ_PREF_FROM 1706
-#endif
-constexpr bool pref_for(int t, int nz) { return t * nz > MIL_YZ_PREF_FROM; }
+// The OTF block is requested before the forward transform where the registers for it do not cost a workgroup per CU: tiles of
+// which a CU holds two anyway (128 registers per thread: T x nz > 1706, and the 8-column tiles from T x nz ~ 600) and whose block
+// is at most 8 float4 per thread.  512 x 256: 191 -> 173 us; 384 x 256 (three workgroups per CU, 80 registers): 126 -> 133 us, so not there.
+constexpr bool pref_for(int t, int nz) {
+    const int cols = cols_for(t, nz), wgs = 163840 / yz_lds_bytes(t, nz, cols);
+    return wgs <= 2 && t * nz * (cols / 2) <= 8 * kYzThreads;
+}
 
 template <int T, int NZ>
 void launch_yz(const YzArgs &a, const float2 *tw_z, int xs, hipStream_t s) {
