@@ -1,5 +1,5 @@
-"""Soak of the RL engine at 512 x 512 x 256: 2 x 5000 single-view iterations on the same inputs, finite and bit-identical.
-Usage (GPU box): python tools/soak_rl.py"""
+"""Soak of the RL engine (512 x 512 x 256, or --shape=nz,ny,nx): 2 x 5000 single-view iterations on the same inputs, finite
+and bit-identical.   Usage (GPU box): python tools/soak_rl.py [--shape=256,384,384]"""
 import os
 import sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,10 @@ import torch
 import fullsize_inputs as fi
 from microimagelib_amd import device as dev
 shape = fi.FULL_SHAPE
+for arg in sys.argv[1:]:
+    if arg.startswith("--shape="):
+        shape = tuple(int(v) for v in arg[len("--shape="):].split(","))
+print("shape", shape)
 A = torch.from_numpy(fi.hash_volume(shape, 1)).cuda(); pa = torch.from_numpy(fi.psf_a()).cuda()
 eng = dev.DeconEngine(shape)
 print("two_pass", eng.two_pass)
