@@ -24,6 +24,9 @@ extern "C" {
 const char *mil_version(void);
 int mil_device_count(void);
 int mil_set_device(int device);               /* cudaSetDevice(deviceNum), src/api_decon.cpp:102 */
+/* cudaMemGetInfo of `device` (src/api_decon.cpp:103, queryDevice) plus what the library's pool holds free on it -- memory a
+ * caller may count as available.  Does not change the calling thread's device. */
+int mil_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
 int mil_snap_transform_size(int n);            /* snapTransformSize, src/api_subfunc.cu:57-87 */
 /* Interpolation weights of every resample / cost kernel: 0 = exact float32 (default), 8 = rounded to 8 fractional bits,
  * emulating the CUDA texture unit the reference samples through (include/cukernel.cuh:510-522, 545-546; rounding to nearest

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mil_version": (C.c_char_p, []),
     "mil_device_count": (C.c_int, []),
     "mil_set_device": (C.c_int, [C.c_int]),
+    "mil_dev_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mil_snap_transform_size": (C.c_int, [C.c_int]),
     "mil_release_cached_memory": (C.c_size_t, []),
     "mil_cached_memory_bytes": (C.c_size_t, []),

@@ -15,8 +15,8 @@
 //                   hands the state on and only then deconvolves.
 // Results, file names and matrix files are those of the single-device run bit for bit; ProcessingLog.txt is written in
 // time-point order whichever worker finishes first.  A device may be listed twice ("0,0"): two workers then share it --
-// which is also what a single device number gets by default (MIL_BATCH_WORKERS_PER_DEVICE=1: one worker, the reference's
-// strictly sequential order).
+// which is also what a single device number gets when the device's free memory holds two time points (else one worker;
+// MIL_BATCH_WORKERS_PER_DEVICE=1: one worker, the reference's strictly sequential order).
 //
 // A time point stays in HBM from the TIFF reader to the TIFF writer (round 5): the stacks are uploaded once -- 16-bit files
 // as 16 bits, widened to float on the device -- and resize / rotate, registration, deconvolution and the projections run on
@@ -82,7 +82,9 @@ void usage(bool full) {
         "30, 31: <int>   Save 3D max projection: X-axis, Y-axis (0 | 1)",
         "32: <int>       Bit of output images (16 or 32)",
         "33: <int>       Query GPU information before processing (0 | 1)",
-        "34: <int>       GPU device",
+        "34: <int>       GPU device; or a comma-separated list (\"0,1,2\": one worker thread per entry, time points dealt",
+        "                round-robin; a device may be listed more than once).  A single device runs two workers when its",
+        "                free memory holds two time points, else one; MIL_BATCH_WORKERS_PER_DEVICE=1..8 forces the number",
         "35, 36: <file>  (optional) backward projectors 1 / 2 [flip of the PSFs]",
     };
     printf("\tOnly 16-bit or 32-bit standard TIFF images are currently supported.\n\n");
@@ -159,15 +161,6 @@ std::vector<int> parse_devices(const char *arg34) {
         pos = comma + 1;
     }
     if (out.empty()) out.push_back(atoi(arg34));
-    // One device named once: TWO workers share it unless MIL_BATCH_WORKERS_PER_DEVICE=1 says otherwise.  A registration is a
-    // chain of ~2 000 dependent cost evaluations with a host round trip between any two, and the readers / writers sit
-    // between the GPU stages of a time point: a second time point in flight fills those gaps (2.76 -> 2.90 time points/s at
-    // 512 x 512 x 256, profiles/r05/bench_cli_batch.json).  Results do not depend on the number of workers.
-    if (out.size() == 1) {
-        const char *per = getenv("MIL_BATCH_WORKERS_PER_DEVICE");
-        const int n = per ? atoi(per) : 2;
-        for (int i = 1; i < n && i < 8; ++i) out.push_back(out[0]);
-    }
     return out;
 }
 
@@ -204,7 +197,7 @@ int main(int argc, char **argv) {
     const bool save_3dx = atoi(argv[30]) != 0, save_3dy = atoi(argv[31]) != 0;
     const unsigned short out_bits = (unsigned short)atoi(argv[32]);
     const bool query = atoi(argv[33]) != 0;
-    const std::vector<int> devices = parse_devices(argv[34]);
+    std::vector<int> devices = parse_devices(argv[34]);
     const int device = devices[0];
     const bool unmatch = argc == 37;
     if (query) queryDevice();
@@ -244,6 +237,27 @@ int main(int argc, char **argv) {
     const long long sx = size[0], sy = size[1], sz = size[2];
     const size_t total = (size_t)sx * sy * sz;
 
+    // ---- workers.  One device named once: TWO workers share it when its memory holds two time points
+    // (MIL_BATCH_WORKERS_PER_DEVICE = 1 .. 8 forces the number).  A registration is a chain of ~2 000 dependent cost
+    // evaluations with a host round trip between any two, and the readers / writers sit between the GPU stages of a time
+    // point: a second time point in flight fills those gaps (3.05 -> 3.25 time points/s at 512 x 512 x 256,
+    // profiles/r05/bench_cli_batch.json).  Results do not depend on the number of workers; ProcessingLog.txt is written in
+    // time-point order either way.  What a worker keeps resident: ~12 stage volumes, the registration's border-padded copies
+    // of the source (3 volumes) and target, and a dual-view engine with its OTFs on the FFT box (~10 volumes): 28 float
+    // volumes is a generous bound.  A device that does not have twice that free -- a smaller part, very large stacks, a
+    // device shared with another process -- runs ONE worker, like the reference's sequential main, instead of ending the
+    // batch when the second worker's allocation fails.
+    if (devices.size() == 1) {
+        const char *per = getenv("MIL_BATCH_WORKERS_PER_DEVICE");
+        int n_workers = per ? atoi(per) : 2;
+        if (!per) {
+            const size_t per_worker = 28 * total * sizeof(float);
+            size_t free_b = 0, total_b = 0;
+            if (mil_dev_mem_info(devices[0], &free_b, &total_b) != 0 || free_b < 2 * per_worker) n_workers = 1;
+        }
+        for (int i = 1; i < n_workers && i < 8; ++i) devices.push_back(devices[0]);
+    }
+
     cli::Volume psf1 = cli::load_tiff(psf1_path), psf2 = cli::load_tiff(psf2_path), bp1, bp2;
     if (!cli::same_size(psf1, psf2)) { printf("\tThe two PSFs don't have the same image size, processing stopped !!!\n"); return 1; }
     if (unmatch) { bp1 = cli::load_tiff(argv[35]); bp2 = cli::load_tiff(argv[36]); }
@@ -274,7 +288,9 @@ int main(int argc, char **argv) {
     auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
     log.direct("\n=== spimFusionBatch: images %d .. %d (step %d), size %lld x %lld x %lld, regMode %d, %d decon iterations\n",
                n_start, n_end, n_step, sx, sy, sz, reg_mode, iters);
-    if (devices.size() > 1) {
+    if (devices.size() == 1) {
+        log.direct("=== 1 worker on GPU device %d\n", devices[0]);
+    } else {
         std::string list;
         for (size_t i = 0; i < devices.size(); ++i) list += (i ? "," : "") + std::to_string(devices[i]);
         log.direct("=== %zu workers on GPU devices %s, time points dealt round-robin\n", devices.size(), list.c_str());
@@ -405,6 +421,12 @@ int main(int argc, char **argv) {
         { std::lock_guard<std::mutex> lock(chain.mu); }  // a waiter is either before its predicate test or asleep
         chain.cv.notify_all();
     };
+    // A time point given up because an EARLIER one failed: its text so far plus one line goes to the log, so that every index a
+    // worker took up has an entry (the ordered log never holds later texts back for an index nobody will publish).
+    auto abandoned = [&](size_t i, Lines &out) {
+        out("\t... abandoned: an earlier time point failed, nothing more of this one is written\n");
+        log.publish((int)i, std::move(out.text));
+    };
     // The registration of time point i according to the mode (:714-843), through `reg` (host or device pointers).
     // 0: registered; kAbandoned: an earlier time point failed, nothing was done; anything else: the status of the library
     // call that failed (libapi.h returns 1 or -1).
@@ -488,21 +510,21 @@ int main(int argc, char **argv) {
                     ahead = std::async(std::launch::async, load_pair, points[ni]);
                 }
             }
-            if (!preprocess(p, dev)) { stop((int)i); break; }
+            if (!preprocess(p, dev)) { out("\t Input image size does not match !!!\n"); log.publish((int)i, std::move(out.text)); stop((int)i); break; }
             cli::Volume &a = *p.a;
             const auto t1 = std::chrono::steady_clock::now();
 
             // ---- registration (:714-843)
             RegState st = base;
             const int reg_status = register_step(i, st, host_reg(p, b_reg, dev), reg_records, out);
-            if (reg_status == kAbandoned) break;
+            if (reg_status == kAbandoned) { abandoned(i, out); break; }
             if (reg_status != 0) {  // a library call failed (its message is on stderr): never write results made from stale buffers
                 out("\t... registration failed (status %d), processing stopped !!!\n", reg_status);
                 log.publish((int)i, std::move(out.text));
                 stop((int)i);
                 break;
             }
-            if (fail_at.load() < (int)i) break;  // an earlier time point failed while this one registered: write nothing
+            if (fail_at.load() < (int)i) { abandoned(i, out); break; }  // an earlier time point failed while this one registered: write nothing
             out("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
                 reg_records[1], reg_records[3], reg_records[7]);
             const std::string ns = std::to_string(n);
@@ -520,7 +542,7 @@ int main(int argc, char **argv) {
                 stop((int)i);
                 break;
             }
-            if (fail_at.load() < (int)i) break;  // an earlier time point failed meanwhile: nothing more of this one is written
+            if (fail_at.load() < (int)i) { abandoned(i, out); break; }  // an earlier time point failed meanwhile: nothing more of this one is written
             out("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
                 decon_records[5]);
             if (behind.valid()) behind.get();  // the previous stack has left decon_out
@@ -662,8 +684,8 @@ int main(int argc, char **argv) {
                     ahead = std::async(std::launch::async, [&read_raw, na, nb, fa, fb] { read_raw(fa, *na); read_raw(fb, *nb); });
                 }
             }
-            if (ra.size[0] != in1[0] || ra.size[1] != in1[1] || ra.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); stop((int)i); break; }
-            if (rb.size[0] != in2[0] || rb.size[1] != in2[1] || rb.size[2] != in2[2]) { printf("\t Input image 2 size does not match !!!\n"); stop((int)i); break; }
+            if (ra.size[0] != in1[0] || ra.size[1] != in1[1] || ra.size[2] != in1[2]) { printf("\t Input image 1 size does not match !!!\n"); out("\t Input image 1 size does not match !!!\n"); log.publish((int)i, std::move(out.text)); stop((int)i); break; }
+            if (rb.size[0] != in2[0] || rb.size[1] != in2[1] || rb.size[2] != in2[2]) { printf("\t Input image 2 size does not match !!!\n"); out("\t Input image 2 size does not match !!!\n"); log.publish((int)i, std::move(out.text)); stop((int)i); break; }
 
             // ---- upload (16-bit files as 16 bits) and widen on the device: (float)v like readtifstack (src/apifunc.cpp:166-183)
             auto to_device = [&](RawStack &r, DevBuf &d_raw, DevBuf &d_in) -> float * {
@@ -709,9 +731,9 @@ int main(int argc, char **argv) {
                 return mil_reg3d(d_b_reg.f(), tmx, reg_a, reg_b, size, size2, choice, aff_method, use_input ? 1 : 0, ftol, it_limit, 1, rec, stream);
             };
             const int reg_status = register_step(i, st, dev_reg, reg_records, out);
-            if (reg_status == kAbandoned) break;
+            if (reg_status == kAbandoned) { abandoned(i, out); break; }
             if (!ok(reg_status, "registration", i, out)) break;
-            if (fail_at.load() < (int)i) break;  // an earlier time point failed while this one registered: write nothing
+            if (fail_at.load() < (int)i) { abandoned(i, out); break; }  // an earlier time point failed while this one registered: write nothing
             out("\t... initial cost function value: %f\n\t... final cost function value: %f\n\t... registration time cost: %2.3f s\n",
                 reg_records[1], reg_records[3], reg_records[7]);
             const std::string ns = std::to_string(n);
@@ -730,7 +752,7 @@ int main(int argc, char **argv) {
             if (!ok(mil_decon_dualview(d_decon.f(), d_a, d_b_reg.f(), size, psf1.data.data(), psf2.data.data(), psf1.size, 0, iters, 1,
                                        decon_records, unmatch ? 1 : 0, bp1.data.data(), bp2.data.data(), stream),
                     "deconvolution", i, out)) break;
-            if (fail_at.load() < (int)i) break;  // an earlier time point failed meanwhile: nothing of this one is written
+            if (fail_at.load() < (int)i) { abandoned(i, out); break; }  // an earlier time point failed meanwhile: nothing of this one is written
             out("\t... Deconvolution time cost: %2.3f s\n\t... GPU free memory after deconvolution is %.0f MBites\n", decon_records[9],
                 decon_records[5]);
             if (behind.valid()) behind.get();  // the previous stack has left h_out

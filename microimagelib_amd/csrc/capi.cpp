@@ -78,6 +78,23 @@ int mil_set_device(int device) {
     return guarded("mil_set_device", [&] { MIL_HIP(hipSetDevice(device)); return 0; });
 }
 
+int mil_dev_mem_info(int device, size_t *free_bytes, size_t *total_bytes) {
+    if (free_bytes) *free_bytes = 0;
+    if (total_bytes) *total_bytes = 0;
+    return guarded("mil_dev_mem_info", [&] {
+        int before = 0;
+        MIL_HIP(hipGetDevice(&before));
+        MIL_HIP(hipSetDevice(device));
+        size_t f = 0, t = 0;
+        const hipError_t e = hipMemGetInfo(&f, &t);
+        MIL_HIP(hipSetDevice(before));
+        MIL_HIP(e);
+        if (free_bytes) *free_bytes = f + pool_cached_bytes_on(device);
+        if (total_bytes) *total_bytes = t;
+        return 0;
+    });
+}
+
 int mil_snap_transform_size(int n) { return snap_transform_size(n); }
 
 int mil_set_texture_weight_bits(int bits) {
@@ -187,7 +204,9 @@ int mil_stream_create(void **stream) {
     });
 }
 void mil_stream_destroy(void *stream) {
-    if (stream) (void)hipStreamDestroy(as_stream(stream));
+    if (!stream) return;
+    k::release_march_ticket(as_stream(stream));
+    (void)hipStreamDestroy(as_stream(stream));
 }
 int mil_stream_sync(void *stream) {
     return guarded("mil_stream_sync", [&] { MIL_HIP(hipStreamSynchronize(as_stream(stream))); return 0; });

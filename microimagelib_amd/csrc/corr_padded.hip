@@ -1038,31 +1038,23 @@ bool use_chunks() {
     return !off;
 }
 
-// Workgroups of a chunked launch: what the device holds at once (occupancy of THAT kernel x compute units), but no more
-// than one per kMinChunk steps.  MIL_CORR_CHUNK_WGS_PER_CU overrides the occupancy (experiments).
+// Workgroups of a chunked launch: a CONSTANT per kernel -- kChunkWgsPerCu x 256, what an MI355X (256 compute units) holds at
+// once when the registers allow as many -- but no more than one per kMinChunk steps.  The grid fixes how many partial sums
+// there are and so the rounding of the two sums: it must not depend on the device a host thread happens to be on, on an
+// occupancy query, or on the compiler's register allocation (round 5 derived it from both; advisor).  A part with fewer
+// compute units, or a build that fits fewer workgroups per unit, runs the same pieces in more than one wave of workgroups:
+// the pieces are independent, nothing waits for a co-resident workgroup.  corr_set_chunk_wgs_per_cu overrides the count
+// (experiments); MIL_CORR_CHUNK=0 is the bit-reference path (the tiled kernels return the bits of kernels 0-2).
 constexpr unsigned kMinChunk = 24;
-// workgroups (of four waves) per compute unit, by kernel 3 .. 6, when the registers allow as many (ms per evaluation at
-// 512 x 512 x 256, identity / 3 deg about y + 2 %, profiles/r05/reg_cost_chunked_ab.txt: kernel 3 with 4 | 5 | 6: 0.146 | 0.146 |
-// 0.142; kernel 5: 0.156 | 0.169 | 0.163 at the identity, 0.176 | 0.183 | 0.180; kernel 6: 0.167 | 0.1645 | 0.170 at 3 deg + 2 %)
+constexpr unsigned kChunkCus = 256;
+// workgroups (of four waves) per compute unit, by kernel 3 .. 6 (ms per evaluation at 512 x 512 x 256, identity / 3 deg about
+// y + 2 %, profiles/r05/reg_cost_chunked_ab.txt: kernel 3 with 4 | 5 | 6: 0.146 | 0.146 | 0.142; kernel 5: 0.156 | 0.169 | 0.163
+// at the identity, 0.176 | 0.183 | 0.180; kernel 6: 0.167 | 0.1645 | 0.170 at 3 deg + 2 %)
 constexpr int kChunkWgsPerCu[4] = {6, 0, 4, 5};
-template <typename K>
-unsigned chunk_grid(K kernel, int which, unsigned long long total_steps) {
-    struct PerDevice { int cus = 0, per_cu = 0; };
-    static PerDevice cache[4][64];  // by kernel and device; filled on first use (benign race: same values)
-    static thread_local int dev = -1;  // the device of this host thread's evaluations (a thread registers on one device)
-    static thread_local int dev_checked = 0;
-    if (dev < 0 || (++dev_checked & 1023) == 0) MIL_HIP(hipGetDevice(&dev));
-    PerDevice &pd = cache[which & 3][dev & 63];
-    if (pd.cus == 0) {
-        int cus = 0, per_cu = 0;
-        MIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        MIL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0));
-        pd.per_cu = std::max(per_cu, 1);
-        pd.cus = std::max(cus, 1);
-    }
-    int per_cu = std::min(pd.per_cu, kChunkWgsPerCu[which & 3]);
+unsigned chunk_grid(int which, unsigned long long total_steps) {
+    int per_cu = kChunkWgsPerCu[which & 3];
     if (const int forced = g_chunk_wgs_per_cu.load(std::memory_order_relaxed)) per_cu = forced;  // experiments
-    const unsigned long long want = (unsigned long long)pd.cus * per_cu;
+    const unsigned long long want = (unsigned long long)kChunkCus * (unsigned)std::max(per_cu, 1);
     const unsigned long long most = (total_steps + kMinChunk - 1) / kMinChunk;
     return (unsigned)std::max(1ull, std::min(want, most));
 }
@@ -1130,7 +1122,7 @@ void corr_sums_padded_async(const float *target, const PaddedSource &src, Dims t
         const unsigned long long total = (unsigned long long)a.gx * a.gy * run_len;
         if (total > 0xffffffffull) throw Error(-1, "corr_sums: volume exceeds launch limits");
         auto launch = [&](auto kern) {
-            const unsigned wgs = chunk_grid(kern, kernel - 3, total);
+            const unsigned wgs = chunk_grid(kernel - 3, total);
             const CorrTail tail = ws.next(wgs, s);
             hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), 0, s, target, volume, a, tail, (unsigned)total, run_len);
         };

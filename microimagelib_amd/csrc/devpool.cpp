@@ -218,6 +218,13 @@ size_t pool_cached_bytes() {
     return n;
 }
 
+size_t pool_cached_bytes_on(int device) {
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lock(pl.mu);
+    auto it = pl.cached_bytes.find(device);
+    return it == pl.cached_bytes.end() ? 0 : it->second;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // roctx hooks of trace.h
 // ---------------------------------------------------------------------------------------------------------------------

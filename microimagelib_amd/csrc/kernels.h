@@ -92,6 +92,7 @@ void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims,
 // pieces of affine_resample (affine.hip, resample_march.hip)
 bool small_source(Dims src);  // fetch_linear_small's range: 32-bit offsets, planes below 2^24 voxels, exact float32 weights
 bool resample_march_eligible(Dims out, Dims src);
+void release_march_ticket(hipStream_t s);  // the stream is about to be destroyed
 void affine_resample_march(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s,
                            bool strict_window);
 bool resample_mip2_eligible(Dims box, Dims src);

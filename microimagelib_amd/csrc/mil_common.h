@@ -45,6 +45,7 @@ void pool_free(void *p) noexcept;               // waits for the whole device fi
 void pool_free_after(void *p, hipStream_t s) noexcept;  // waits for `s` only: the caller knows no other stream uses p
 size_t pool_release_all();  // hipFree everything cached; returns the bytes given back
 size_t pool_cached_bytes();  // bytes currently kept for reuse (all devices)
+size_t pool_cached_bytes_on(int device);
 
 // RAII device buffer.
 template <class T>

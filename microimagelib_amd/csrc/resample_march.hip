@@ -22,6 +22,8 @@
 #include <type_traits>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -280,10 +282,6 @@ __global__ __launch_bounds__(kThreads) void resample_march_kernel(float *__restr
             }
         }
     }
-    // the workgroup that draws the LAST ticket beyond the pieces (n_pieces + gridDim.x - 1: every workgroup draws exactly one
-    // such ticket, after all its work) re-arms the counter for the next launch on this stream
-    if (threadIdx.x == 0 && mine == n_pieces + gridDim.x - 1u)
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -520,38 +518,74 @@ unsigned march_grid(K kernel, int which, unsigned long long total_steps) {
     return (unsigned)std::max(1ull, std::min(want, most));
 }
 
-// One ticket counter per (device, stream): kernels of one stream run one after the other and the last workgroup of each
-// re-arms the counter, so a slot is only ever in use by one launch.  Slots live for the life of the process (4 bytes each).
-unsigned *ticket_of(hipStream_t s) {
-    struct Slot { int dev; hipStream_t s; unsigned *p; };
-    static std::mutex mu;
-    static std::vector<Slot> slots;
-    static std::vector<std::pair<int, unsigned *>> blocks;  // (device, next free word of a 4 KB block)
-    static std::vector<std::pair<int, int>> block_left;
+// Ticket counters.  Every launch is self-contained: the host zeroes the launch's counter on the launch's own stream right
+// before the kernel (a 4-byte hipMemsetAsync: ~2 us beside a 150 us kernel, and a memset node under graph capture), so a
+// launch never depends on what an earlier one -- finished, faulted or abandoned -- left in it.  A counter belongs to ONE
+// stream (launches of a stream run one after the other, so it is only ever used by one launch at a time); the per-thread
+// stream handle names a different stream in every host thread and is keyed by the thread as well.  mil_stream_destroy hands
+// a stream's counter back (release_march_ticket); counters of foreign streams live for the life of the process, 4 bytes each.
+struct TicketKey {
+    int dev;
+    hipStream_t s;
+    std::thread::id tid;  // only for hipStreamPerThread
+    bool operator==(const TicketKey &o) const { return dev == o.dev && s == o.s && tid == o.tid; }
+};
+struct TicketKeyHash {
+    size_t operator()(const TicketKey &k) const {
+        return std::hash<const void *>()(k.s) * 1000003u ^ std::hash<std::thread::id>()(k.tid) * 31u ^ (size_t)k.dev;
+    }
+};
+struct TicketTable {
+    std::mutex mu;
+    std::unordered_map<TicketKey, unsigned *, TicketKeyHash> slots;
+    std::vector<std::pair<int, unsigned *>> free_words;  // (device, word)
+};
+TicketTable &tickets() {
+    static TicketTable *t = new TicketTable;  // never destroyed: streams may be released during process teardown
+    return *t;
+}
+TicketKey ticket_key(hipStream_t s) {
     int dev = 0;
     MIL_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> g(mu);
-    for (const Slot &sl : slots)
-        if (sl.dev == dev && sl.s == s) return sl.p;
-    size_t b = 0;
-    for (; b < blocks.size(); ++b)
-        if (blocks[b].first == dev && block_left[b].second > 0) break;
-    if (b == blocks.size()) {
+    return TicketKey{dev, s, s == hipStreamPerThread ? std::this_thread::get_id() : std::thread::id()};
+}
+unsigned *ticket_of(hipStream_t s) {
+    const TicketKey key = ticket_key(s);
+    TicketTable &t = tickets();
+    std::lock_guard<std::mutex> g(t.mu);
+    auto it = t.slots.find(key);
+    if (it != t.slots.end()) return it->second;
+    size_t f = 0;
+    for (; f < t.free_words.size(); ++f)
+        if (t.free_words[f].first == key.dev) break;
+    if (f == t.free_words.size()) {  // a 4 KB block of 1024 counters; contents do not matter (zeroed per launch)
         unsigned *p = nullptr;
         MIL_HIP(hipMalloc((void **)&p, 4096));
-        MIL_HIP(hipMemset(p, 0, 4096));
-        MIL_HIP(hipDeviceSynchronize());  // once per 1024 streams of a device
-        blocks.push_back({dev, p});
-        block_left.push_back({dev, 1024});
+        for (int i = 1023; i >= 0; --i) t.free_words.push_back({key.dev, p + i});
+        f = t.free_words.size() - 1;
     }
-    unsigned *p = blocks[b].second;
-    blocks[b].second += 1;
-    block_left[b].second -= 1;
-    slots.push_back({dev, s, p});
+    unsigned *p = t.free_words[f].second;
+    t.free_words.erase(t.free_words.begin() + (long)f);
+    t.slots.emplace(key, p);
     return p;
 }
 
 }  // namespace
+
+// The stream is about to be destroyed (mil_stream_destroy): its counter goes back to the free list of its device.
+void release_march_ticket(hipStream_t s) {
+    if (s == hipStreamPerThread || s == nullptr) return;
+    TicketTable &t = tickets();
+    std::lock_guard<std::mutex> g(t.mu);
+    for (auto it = t.slots.begin(); it != t.slots.end();) {
+        if (it->first.s == s) {
+            t.free_words.push_back({it->first.dev, it->second});
+            it = t.slots.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
 
 // Volumes the marching kernel takes: fetch_linear_small's range (below 2 GiB, planes below 2^24 voxels, sx >= 2, exact
 // float32 weights) and an output whose byte offsets fit 32 bits.  MIL_RESAMPLE_MARCH=0 keeps the one-voxel kernel (A/B).
@@ -580,6 +614,7 @@ void affine_resample_march(float *out, const float *src, Dims o, Dims sd, const 
     const unsigned long long pieces = (unsigned long long)a.gx * a.gy * ((run_len + kPiece - 1) / kPiece);
     if (pieces > 0x7fffffffull) throw Error(-1, "affine_resample: volume exceeds launch limits");
     unsigned *ticket = ticket_of(s);
+    MIL_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), s));
     auto launch = [&](auto kern, int which) {
         const unsigned wgs = march_grid(kern, which, pieces * kPiece);
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), 0, s, out, src, a, ticket, run_len);

@@ -104,6 +104,14 @@ thread_local int t_device = 0;
 }
 
 extern "C" int mil_set_device(int device) { t_device = device; return 0; }
+// STUB_DEVICE_FREE_BYTES: what the "device" reports free (default: plenty) -- the tool's choice of one or two workers
+extern "C" int mil_dev_mem_info(int, size_t *free_bytes, size_t *total_bytes) {
+    const char *e = getenv("STUB_DEVICE_FREE_BYTES");
+    const size_t f = e ? (size_t)atoll(e) : (size_t)64 << 30;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = (size_t)64 << 30;
+    return 0;
+}
 extern "C" int mil_dev_alloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); return *p ? 0 : -1; }
 extern "C" void mil_dev_free(void *p) { free(p); }
 extern "C" int mil_host_alloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); return *p ? 0 : -1; }

@@ -117,6 +117,31 @@ def test_device_list_from_the_environment(tmp_path, tool):
     assert "2 workers on GPU devices 0,0" in open(out / "ProcessingLog.txt").read()
 
 
+def test_a_single_device_gets_two_workers_only_when_two_time_points_fit(tmp_path, tool):
+    """One device named once: two workers when the device reports room for two time points (28 float volumes each), one --
+    the reference's sequential order -- when it does not, instead of a second worker whose allocation ends the batch.
+    MIL_BATCH_WORKERS_PER_DEVICE forces the number either way.  Same files in every case."""
+    _series(tmp_path, 4)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    per_worker = 28 * 4 * 6 * 10 * 12
+    trees = {}
+    for name, extra, want in (("roomy", {}, "2 workers on GPU devices 0,0"),
+                              ("tight", {"STUB_DEVICE_FREE_BYTES": str(2 * per_worker - 1)}, "1 worker on GPU device 0"),
+                              ("exact", {"STUB_DEVICE_FREE_BYTES": str(2 * per_worker)}, "2 workers on GPU devices 0,0"),
+                              ("forced1", {"MIL_BATCH_WORKERS_PER_DEVICE": "1"}, "1 worker on GPU device 0"),
+                              ("forced3", {"MIL_BATCH_WORKERS_PER_DEVICE": "3", "STUB_DEVICE_FREE_BYTES": "1"},
+                               "3 workers on GPU devices 0,0,0")):
+        out = tmp_path / f"out_{name}"
+        r = subprocess.run([tool] + _args(tmp_path, out, 3, "0", 4), capture_output=True, text=True, timeout=600,
+                           env=dict(env, **extra))
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+        assert want in open(out / "ProcessingLog.txt").read(), name
+        trees[name] = _tree(out)
+    for name, t in trees.items():
+        assert t == trees["roomy"], name
+
+
 @pytest.mark.parametrize("devices", ["0", "0,0"])
 def test_a_failed_library_call_stops_the_batch(tmp_path, tool, devices):
     """A registration call that fails (the library prints its error and returns non-zero without touching the outputs) must not

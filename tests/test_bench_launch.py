@@ -99,3 +99,8 @@ def test_a_hanging_extra_is_ended_by_the_watchdog():
     out = _line(p)
     assert out["extra"]["errors"][-1]["extra"] == "hang" and "deadline" in out["extra"]["errors"][-1]["error"]
     assert "regmode3" in out["extra"]["batch_config5_by_mode"]  # what had finished is in the line
+    assert out["extras_truncated"] is True  # top level: the reader of the line sees the run was cut short
+    # a CI that wants a truncated run to FAIL asks for it: same line, non-zero status
+    p = _run(["--dry-run", "--extras-deadline", "3"] + BATCH, {"MIL_BENCH_DRY_RUN_HANG": "0", "MIL_BENCH_DEADLINE_RC": "3"})
+    assert p.returncode == 3, p.stderr[-2000:]
+    assert _line(p)["extras_truncated"] is True
