@@ -66,7 +66,8 @@ __device__ __forceinline__ f32x2 gather_pair(__amdgpu_buffer_rsrc_t rsrc, unsign
 // about y; otherwise along z, reusing source planes.  STRICT: the 2-D variant's window 0 < t (affineTransform2Dkernel).
 template <bool MARCHY, bool STRICT>
 __global__ __launch_bounds__(kThreads) void resample_march_kernel(float *__restrict__ out, const float *__restrict__ src,
-                                                                MarchArgs a, unsigned *__restrict__ ticket, int run_len) {
+                                                                MarchArgs a, unsigned long long *__restrict__ ticket, unsigned epoch,
+                                                                int run_len) {
     __shared__ unsigned next_piece;
     const int lane = threadIdx.x & (kLanes - 1), wave = threadIdx.x / kLanes;
     const f32x2 half2 = {0.5f, 0.5f};
@@ -83,15 +84,23 @@ __global__ __launch_bounds__(kThreads) void resample_march_kernel(float *__restr
     // is worked on, so its round trip is hidden.
     const unsigned pieces_per_run = (unsigned)((run_len + kPiece - 1) / kPiece);
     const unsigned n_pieces = pieces_per_run * (unsigned)a.gx * (unsigned)a.gy;
+    // The counter is (epoch << 32 | tickets drawn in that epoch) and every launch brings its own, larger epoch: the first
+    // draw of a workgroup raises the word to (epoch << 32) if it is still below -- whatever an earlier launch left there,
+    // finished or not -- so a launch depends on nothing but its own arguments (ticket_of, below).
+    const unsigned long long origin = (unsigned long long)epoch << 32;
+    auto draw = [&] { return (unsigned)(__hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - origin); };
     unsigned mine = 0;
-    if (threadIdx.x == 0) mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_max(ticket, origin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine = draw();
+    }
     for (;;) {
         if (threadIdx.x == 0) next_piece = mine;
         __syncthreads();
         const unsigned piece = next_piece;
         __syncthreads();  // everybody has read it before thread 0 writes the next one
         if (piece >= n_pieces) break;
-        if (threadIdx.x == 0) mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) mine = draw();
         const unsigned col = piece / pieces_per_run;
         const int s0 = (int)(piece - col * pieces_per_run) * kPiece;
         const int s1 = min(run_len, s0 + kPiece);
@@ -518,12 +527,15 @@ unsigned march_grid(K kernel, int which, unsigned long long total_steps) {
     return (unsigned)std::max(1ull, std::min(want, most));
 }
 
-// Ticket counters.  Every launch is self-contained: the host zeroes the launch's counter on the launch's own stream right
-// before the kernel (a 4-byte hipMemsetAsync: ~2 us beside a 150 us kernel, and a memset node under graph capture), so a
-// launch never depends on what an earlier one -- finished, faulted or abandoned -- left in it.  A counter belongs to ONE
-// stream (launches of a stream run one after the other, so it is only ever used by one launch at a time); the per-thread
-// stream handle names a different stream in every host thread and is keyed by the thread as well.  mil_stream_destroy hands
-// a stream's counter back (release_march_ticket); counters of foreign streams live for the life of the process, 4 bytes each.
+// Ticket counters.  Every launch is self-contained: the counter word is (epoch << 32 | tickets drawn) and the host hands
+// each launch the word's next epoch, which the kernel's first draw installs with an atomic max -- no reset between launches,
+// no dependence on what an earlier launch (finished, faulted or abandoned) left in the word, no extra launch (a 4-byte
+// hipMemsetAsync in front of every resample cost 3-4 us of 150).  A word is zeroed on its stream before its first use, when
+// its epoch wraps, and -- as a memset NODE -- in front of a launch that is being captured into a graph, so that every replay
+// starts below the captured epoch.  A word belongs to ONE stream (launches of a stream run one after the other, so it is only
+// ever used by one launch at a time); the per-thread stream handle names a different stream in every host thread and is keyed
+// by the thread as well.  mil_stream_destroy hands a stream's word back WITH its epoch (release_march_ticket); words of foreign
+// streams live for the life of the process, 8 bytes each.
 struct TicketKey {
     int dev;
     hipStream_t s;
@@ -535,39 +547,54 @@ struct TicketKeyHash {
         return std::hash<const void *>()(k.s) * 1000003u ^ std::hash<std::thread::id>()(k.tid) * 31u ^ (size_t)k.dev;
     }
 };
+struct TicketWord {
+    int dev = 0;
+    unsigned long long *p = nullptr;
+    unsigned epoch = 0;  // of the last launch; 0: never used, contents undefined
+};
 struct TicketTable {
     std::mutex mu;
-    std::unordered_map<TicketKey, unsigned *, TicketKeyHash> slots;
-    std::vector<std::pair<int, unsigned *>> free_words;  // (device, word)
+    std::unordered_map<TicketKey, TicketWord, TicketKeyHash> slots;
+    std::vector<TicketWord> free_words;
 };
 TicketTable &tickets() {
     static TicketTable *t = new TicketTable;  // never destroyed: streams may be released during process teardown
     return *t;
 }
-TicketKey ticket_key(hipStream_t s) {
-    int dev = 0;
-    MIL_HIP(hipGetDevice(&dev));
-    return TicketKey{dev, s, s == hipStreamPerThread ? std::this_thread::get_id() : std::thread::id()};
-}
-unsigned *ticket_of(hipStream_t s) {
-    const TicketKey key = ticket_key(s);
+struct Ticket {
+    unsigned long long *p;
+    unsigned epoch;
+};
+// the word of stream `s` and the epoch of the launch about to be queued on it
+Ticket ticket_of(hipStream_t s) {
+    TicketKey key{0, s, s == hipStreamPerThread ? std::this_thread::get_id() : std::thread::id()};
+    MIL_HIP(hipGetDevice(&key.dev));
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        capture = hipStreamCaptureStatusNone;
+    }
     TicketTable &t = tickets();
     std::lock_guard<std::mutex> g(t.mu);
     auto it = t.slots.find(key);
-    if (it != t.slots.end()) return it->second;
-    size_t f = 0;
-    for (; f < t.free_words.size(); ++f)
-        if (t.free_words[f].first == key.dev) break;
-    if (f == t.free_words.size()) {  // a 4 KB block of 1024 counters; contents do not matter (zeroed per launch)
-        unsigned *p = nullptr;
-        MIL_HIP(hipMalloc((void **)&p, 4096));
-        for (int i = 1023; i >= 0; --i) t.free_words.push_back({key.dev, p + i});
-        f = t.free_words.size() - 1;
+    if (it == t.slots.end()) {
+        size_t f = 0;
+        for (; f < t.free_words.size(); ++f)
+            if (t.free_words[f].dev == key.dev) break;
+        if (f == t.free_words.size()) {  // a 4 KB block of 512 words
+            unsigned long long *p = nullptr;
+            MIL_HIP(hipMalloc((void **)&p, 4096));
+            for (int i = 511; i >= 0; --i) t.free_words.push_back(TicketWord{key.dev, p + i, 0u});
+            f = t.free_words.size() - 1;
+        }
+        it = t.slots.emplace(key, t.free_words[f]).first;
+        t.free_words.erase(t.free_words.begin() + (long)f);
     }
-    unsigned *p = t.free_words[f].second;
-    t.free_words.erase(t.free_words.begin() + (long)f);
-    t.slots.emplace(key, p);
-    return p;
+    TicketWord &w = it->second;
+    const bool fresh = w.epoch == 0;
+    if (++w.epoch == 0) w.epoch = 1;  // wrapped
+    if (fresh || w.epoch == 1 || capture != hipStreamCaptureStatusNone) MIL_HIP(hipMemsetAsync(w.p, 0, sizeof(unsigned long long), s));
+    return Ticket{w.p, w.epoch};
 }
 
 }  // namespace
@@ -579,7 +606,7 @@ void release_march_ticket(hipStream_t s) {
     std::lock_guard<std::mutex> g(t.mu);
     for (auto it = t.slots.begin(); it != t.slots.end();) {
         if (it->first.s == s) {
-            t.free_words.push_back({it->first.dev, it->second});
+            t.free_words.push_back(it->second);  // with its epoch: the next owner continues above what the word holds
             it = t.slots.erase(it);
         } else {
             ++it;
@@ -613,11 +640,10 @@ void affine_resample_march(float *out, const float *src, Dims o, Dims sd, const 
     a.gy = ((march_y ? a.tz : a.ty) + kWaves - 1) / kWaves;
     const unsigned long long pieces = (unsigned long long)a.gx * a.gy * ((run_len + kPiece - 1) / kPiece);
     if (pieces > 0x7fffffffull) throw Error(-1, "affine_resample: volume exceeds launch limits");
-    unsigned *ticket = ticket_of(s);
-    MIL_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), s));
+    const Ticket ticket = ticket_of(s);
     auto launch = [&](auto kern, int which) {
         const unsigned wgs = march_grid(kern, which, pieces * kPiece);
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), 0, s, out, src, a, ticket, run_len);
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), 0, s, out, src, a, ticket.p, ticket.epoch, run_len);
     };
     if (march_y && strict_window) launch(resample_march_kernel<true, true>, 0);
     else if (march_y) launch(resample_march_kernel<true, false>, 1);
