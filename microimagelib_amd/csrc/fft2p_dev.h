@@ -397,9 +397,9 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
                 float2 *w = u + 4 * za2;
                 dft4<-1>(w[0], w[1], w[2], w[3]);
                 if (sp) {
-                    w[1] = c_add(w[1], rot90<-1>(w[1])) * make_float2(h8, h8);
+                    w[1] = add_i<-1>(w[1], w[1]) * make_float2(h8, h8);
                     w[2] = rot90<-1>(w[2]);
-                    w[3] = c_sub(rot90<-1>(w[3]), w[3]) * make_float2(h8, h8);
+                    w[3] = add_i<+1>(w[3], w[3]) * make_float2(-h8, -h8);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -428,9 +428,9 @@ __global__ __launch_bounds__(32 * COLS, 2) void yz_conv_kernel(YzArgs a) {
                     w[k] = sp ? c_sub(oth, w[k]) : c_add(w[k], oth);
                 }
                 if (sp) {
-                    w[1] = c_add(w[1], rot90<+1>(w[1])) * make_float2(h8, h8);
+                    w[1] = add_i<+1>(w[1], w[1]) * make_float2(h8, h8);
                     w[2] = rot90<+1>(w[2]);
-                    w[3] = c_sub(rot90<+1>(w[3]), w[3]) * make_float2(h8, h8);
+                    w[3] = add_i<-1>(w[3], w[3]) * make_float2(-h8, -h8);
                 }
                 dft4<+1>(w[0], w[1], w[2], w[3]);
             }

@@ -34,6 +34,19 @@ template <int SIGN>
 __device__ __forceinline__ float2 rot90(float2 a) {
     return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
 }
+// a + SIGN * i * b and (SIGN * i * a) * s as ONE packed instruction each: b's halves swapped by op_sel, the sign in a constant
+// vector ((-1, 1) or (1, -1) from an SGPR pair, a multiplication by one: exact, same bits as a + rot90(b)).  Written as
+// c_add(a, rot90(b)) the compiler first BUILDS the rotated vector (v_xor_b32 + v_mov_b32: it folds a swap and a sign into
+// the operands of v_pk_mul / v_pk_fma, not into v_pk_add's): 10 of the 36 vector instructions of a radix-8 butterfly,
+// 620 of the 3 300 of the xy kernel (round 6).
+template <int SIGN>
+__device__ __forceinline__ float2 add_i(float2 a, float2 b) {
+    return make_float2(b.y, b.x) * (SIGN > 0 ? make_float2(-1.f, 1.f) : make_float2(1.f, -1.f)) + a;
+}
+template <int SIGN>
+__device__ __forceinline__ float2 rot_mul(float2 a, float s) {
+    return make_float2(a.y, a.x) * (SIGN > 0 ? make_float2(-s, s) : make_float2(s, -s));
+}
 
 template <int SIGN>
 __device__ __forceinline__ void dft2(float2 *v) {
@@ -45,11 +58,11 @@ __device__ __forceinline__ void dft2(float2 *v) {
 template <int SIGN>
 __device__ __forceinline__ void dft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3) {
     float2 a0 = c_add(v0, v2), a1 = c_sub(v0, v2);
-    float2 a2 = c_add(v1, v3), a3 = rot90<SIGN>(c_sub(v1, v3));
+    float2 a2 = c_add(v1, v3), a3 = c_sub(v1, v3);
     v0 = c_add(a0, a2);
     v2 = c_sub(a0, a2);
-    v1 = c_add(a1, a3);
-    v3 = c_sub(a1, a3);
+    v1 = add_i<SIGN>(a1, a3);
+    v3 = add_i<-SIGN>(a1, a3);
 }
 
 template <int SIGN>
@@ -59,18 +72,17 @@ __device__ __forceinline__ void dft8(float2 *v) {
     dft4<SIGN>(v[1], v[3], v[5], v[7]);  // odd part,  outputs O[0..3] in v1,v3,v5,v7
     float2 o1 = v[3], o2 = v[5], o3 = v[7];
     // w8^1, w8^2, w8^3 with w8 = exp(SIGN*i*pi/4):  (1 + SIGN i) / sqrt2,  SIGN i,  (-1 + SIGN i) / sqrt2
-    o1 = c_add(o1, rot90<SIGN>(o1)) * make_float2(h, h);
-    o3 = c_sub(rot90<SIGN>(o3), o3) * make_float2(h, h);
-    o2 = rot90<SIGN>(o2);
+    o1 = add_i<SIGN>(o1, o1);   // times h below
+    o3 = add_i<-SIGN>(o3, o3);  // (SIGN i o3 - o3) = -this
     float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
     v[0] = c_add(e0, o0);
     v[4] = c_sub(e0, o0);
-    v[1] = c_add(e1, o1);
-    v[5] = c_sub(e1, o1);
-    v[2] = c_add(e2, o2);
-    v[6] = c_sub(e2, o2);
-    v[3] = c_add(e3, o3);
-    v[7] = c_sub(e3, o3);
+    v[1] = o1 * make_float2(h, h) + e1;  // each product has ONE use: contracted into the sum (v_pk_fma_f32)
+    v[5] = o1 * make_float2(-h, -h) + e1;
+    v[2] = add_i<SIGN>(e2, o2);
+    v[6] = add_i<-SIGN>(e2, o2);
+    v[3] = o3 * make_float2(-h, -h) + e3;
+    v[7] = o3 * make_float2(h, h) + e3;
 }
 
 // a * w16^M, w16 = exp(SIGN * 2 pi i / 16), M known at compile time
@@ -79,13 +91,13 @@ __device__ __forceinline__ float2 mul_w16(float2 a) {
     constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
     if constexpr (M == 0) return a;
     else if constexpr (M == 4) return rot90<SIGN>(a);
-    else if constexpr (M == 2) return c_add(a, rot90<SIGN>(a)) * make_float2(h, h);
-    else if constexpr (M == 6) return c_sub(rot90<SIGN>(a), a) * make_float2(h, h);
+    else if constexpr (M == 2) return add_i<SIGN>(a, a) * make_float2(h, h);
+    else if constexpr (M == 6) return add_i<-SIGN>(a, a) * make_float2(-h, -h);
     else {  // a * (cos t + SIGN i sin t) = a cos t + rot90(a) sin t
         static_assert(M == 1 || M == 3 || M == 9, "mul_w16: exponent not used by dft16");
         constexpr float c = (M == 1) ? c1 : (M == 3) ? s1 : -c1;
         constexpr float s = (M == 1) ? s1 : (M == 3) ? c1 : -s1;
-        return a * make_float2(c, c) + rot90<SIGN>(a) * make_float2(s, s);
+        return a * make_float2(c, c) + rot_mul<SIGN>(a, s);
     }
 }
 
@@ -171,9 +183,8 @@ __device__ __forceinline__ void dft_odd(float2 *v) {
             q.x += b[j].x * OddTable<R>::s[e];
             q.y += b[j].y * OddTable<R>::s[e];
         }
-        const float2 iq = (SIGN > 0) ? make_float2(-q.y, q.x) : make_float2(q.y, -q.x);  // SIGN * i * q
-        v[k] = c_add(p, iq);
-        v[R - k] = c_sub(p, iq);
+        v[k] = add_i<SIGN>(p, q);  // p +/- SIGN * i * q
+        v[R - k] = add_i<-SIGN>(p, q);
     }
 }
 
@@ -260,7 +271,7 @@ __device__ __forceinline__ float2 mul_wr(float2 a) {
     else if constexpr (c == -1.0f) return make_float2(-a.x, -a.y);
     else if constexpr (c == 0.0f && s == 1.0f) return rot90<SIGN>(a);
     else if constexpr (c == 0.0f && s == -1.0f) return rot90<-SIGN>(a);
-    else return a * make_float2(c, c) + rot90<SIGN>(a) * make_float2(s, s);
+    else return a * make_float2(c, c) + rot_mul<SIGN>(a, s);
 }
 
 template <int R, int SIGN>
