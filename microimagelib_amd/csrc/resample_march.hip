@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -42,7 +43,7 @@ constexpr int kThreads = kLanes * kWaves;
 #endif
 constexpr int kPiece = MARCH_PIECE;    // steps of one column a workgroup draws at a time; off the rim or not is decided per piece
 constexpr unsigned kMinChunk = 32;
-constexpr int kWgsPerCu = 6;
+constexpr int kWgsPerCu = 10;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -66,8 +67,8 @@ __device__ __forceinline__ f32x2 gather_pair(__amdgpu_buffer_rsrc_t rsrc, unsign
 // about y; otherwise along z, reusing source planes.  STRICT: the 2-D variant's window 0 < t (affineTransform2Dkernel).
 template <bool MARCHY, bool STRICT>
 __global__ __launch_bounds__(kThreads) void resample_march_kernel(float *__restrict__ out, const float *__restrict__ src,
-                                                                MarchArgs a, unsigned long long *__restrict__ ticket, unsigned epoch,
-                                                                int run_len) {
+                                                                MarchArgs a, unsigned *__restrict__ ticket,
+                                                                unsigned *__restrict__ next_ticket, int run_len) {
     __shared__ unsigned next_piece;
     const int lane = threadIdx.x & (kLanes - 1), wave = threadIdx.x / kLanes;
     const f32x2 half2 = {0.5f, 0.5f};
@@ -84,16 +85,14 @@ __global__ __launch_bounds__(kThreads) void resample_march_kernel(float *__restr
     // is worked on, so its round trip is hidden.
     const unsigned pieces_per_run = (unsigned)((run_len + kPiece - 1) / kPiece);
     const unsigned n_pieces = pieces_per_run * (unsigned)a.gx * (unsigned)a.gy;
-    // The counter is (epoch << 32 | tickets drawn in that epoch) and every launch brings its own, larger epoch: the first
-    // draw of a workgroup raises the word to (epoch << 32) if it is still below -- whatever an earlier launch left there,
-    // finished or not -- so a launch depends on nothing but its own arguments (ticket_of, below).
-    const unsigned long long origin = (unsigned long long)epoch << 32;
-    auto draw = [&] { return (unsigned)(__hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - origin); };
-    unsigned mine = 0;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_max(ticket, origin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mine = draw();
-    }
+    // A workgroup's FIRST piece is its own number, the others come from the counter (ticket t = piece gridDim.x + t): one atomic
+    // per piece on a single address is what the pieces cost beyond their work -- ~5 ns each, serialised (with a second atomic
+    // per workgroup to install an epoch in a 64-bit word, 2 560 more of them, the identity resample ran 0.158 instead of
+    // 0.146 ms: profiles/r06/resample_ticket.txt).  The counter of THIS launch is zero when it starts -- the previous launch of
+    // the stream zeroed it while it ran on the other word of the pair (ticket_of, below) -- and this launch zeroes the next one's.
+    auto draw = [&] { return gridDim.x + __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(next_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned mine = blockIdx.x;
     for (;;) {
         if (threadIdx.x == 0) next_piece = mine;
         __syncthreads();
@@ -506,36 +505,37 @@ void exception_rates(const float *m, double &along_z, double &along_y) {
     along_y = std::fabs((double)m[1]) * px + std::fabs((double)m[5] - 1.0) * py + std::fabs((double)m[9]) * pz;
 }
 
-template <typename K>
-unsigned march_grid(K kernel, int which, unsigned long long total_steps) {
-    struct PerDevice { int cus = 0, per_cu = 0; };
-    static PerDevice cache[4][64];
+// Workgroups of a marching resample: kWgsPerCu per compute unit -- twice what a compute unit holds at once (five), so that
+// 2 560 of the 4 096 pieces of a 512 x 512 x 256 volume are somebody's first piece and the counter hands out the rest.
+// Swept on one box (tools/sweep_resample_wgs.py, profiles/r06/resample_ticket.txt; identity | 3 deg + 2 % | 10 deg about z, ms):
+// 6: 0.128 | 0.142 | 0.170, 8: 0.123 | 0.143 | 0.158, 10: 0.122 | 0.138 | 0.146, 12: 0.131 | 0.146 | 0.157, 16 (one piece
+// each, no counter): 0.140 | 0.159 | 0.161.  The output does not depend on the grid.
+unsigned march_grid(unsigned long long total_steps) {
+    static std::atomic<int> cus_of[64];  // compute units by device number (0: not asked yet)
     int dev = 0;
     MIL_HIP(hipGetDevice(&dev));
-    PerDevice &pd = cache[which & 3][dev & 63];
-    if (pd.cus == 0) {
-        int cus = 0, per_cu = 0;
+    int cus = dev < 64 ? cus_of[dev].load(std::memory_order_relaxed) : 0;
+    if (cus == 0) {
         MIL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        MIL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0));
-        pd.per_cu = std::max(per_cu, 1);
-        pd.cus = std::max(cus, 1);
+        cus = std::max(cus, 1);
+        if (dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
     }
-    int per_cu = std::min(pd.per_cu, kWgsPerCu);
+    int per_cu = kWgsPerCu;
     if (const char *e = getenv("MIL_RESAMPLE_WGS_PER_CU")) per_cu = std::max(1, atoi(e));
-    const unsigned long long want = (unsigned long long)pd.cus * per_cu;
+    const unsigned long long want = (unsigned long long)cus * per_cu;
     const unsigned long long most = (total_steps + kMinChunk - 1) / kMinChunk;
     return (unsigned)std::max(1ull, std::min(want, most));
 }
 
-// Ticket counters.  Every launch is self-contained: the counter word is (epoch << 32 | tickets drawn) and the host hands
-// each launch the word's next epoch, which the kernel's first draw installs with an atomic max -- no reset between launches,
-// no dependence on what an earlier launch (finished, faulted or abandoned) left in the word, no extra launch (a 4-byte
-// hipMemsetAsync in front of every resample cost 3-4 us of 150).  A word is zeroed on its stream before its first use, when
-// its epoch wraps, and -- as a memset NODE -- in front of a launch that is being captured into a graph, so that every replay
-// starts below the captured epoch.  A word belongs to ONE stream (launches of a stream run one after the other, so it is only
-// ever used by one launch at a time); the per-thread stream handle names a different stream in every host thread and is keyed
-// by the thread as well.  mil_stream_destroy hands a stream's word back WITH its epoch (release_march_ticket); words of foreign
-// streams live for the life of the process, 8 bytes each.
+// Ticket counters.  A stream owns a PAIR of 32-bit counters and its launches alternate between them: launch n draws from word
+// n % 2, which launch n - 1 zeroed while it ran (its first workgroup, a plain agent-scope store; launches of a stream run one
+// after the other, so nobody else touches that word meanwhile), and zeroes word (n + 1) % 2 for its successor -- no reset launch
+// between resamples (a 4-byte hipMemsetAsync in front of every resample cost 3-4 us of 150), no re-arming by "the last
+// workgroup", nothing that depends on how far an earlier launch got.  The host zeroes both words on the stream before the
+// pair's first use, and -- as memset NODES around the kernel -- when the launch is being captured into a graph, so that every
+// replay finds its word zero and leaves both words zero for whatever runs next on the stream.  The per-thread stream handle names
+// a different stream in every host thread and is keyed by the thread as well.  mil_stream_destroy hands a stream's pair back
+// with its launch count (release_march_ticket); pairs of foreign streams live for the life of the process, 8 bytes each.
 struct TicketKey {
     int dev;
     hipStream_t s;
@@ -549,8 +549,9 @@ struct TicketKeyHash {
 };
 struct TicketWord {
     int dev = 0;
-    unsigned long long *p = nullptr;
-    unsigned epoch = 0;  // of the last launch; 0: never used, contents undefined
+    unsigned *p = nullptr;   // the pair
+    unsigned launches = 0;   // queued on the pair so far
+    bool fresh = true;       // never used: contents undefined
 };
 struct TicketTable {
     std::mutex mu;
@@ -562,10 +563,11 @@ TicketTable &tickets() {
     return *t;
 }
 struct Ticket {
-    unsigned long long *p;
-    unsigned epoch;
+    unsigned *cur, *next;
+    bool captured;  // the launch is being recorded into a graph: zero `cur` again behind the kernel
 };
-// the word of stream `s` and the epoch of the launch about to be queued on it
+// the counters of the launch about to be queued on stream `s`; the caller holds tickets().mu until that launch IS queued (two
+// host threads queuing on one stream must enter the stream in the order in which they were dealt their words)
 Ticket ticket_of(hipStream_t s) {
     TicketKey key{0, s, s == hipStreamPerThread ? std::this_thread::get_id() : std::thread::id()};
     MIL_HIP(hipGetDevice(&key.dev));
@@ -575,26 +577,28 @@ Ticket ticket_of(hipStream_t s) {
         capture = hipStreamCaptureStatusNone;
     }
     TicketTable &t = tickets();
-    std::lock_guard<std::mutex> g(t.mu);
     auto it = t.slots.find(key);
     if (it == t.slots.end()) {
         size_t f = 0;
         for (; f < t.free_words.size(); ++f)
             if (t.free_words[f].dev == key.dev) break;
-        if (f == t.free_words.size()) {  // a 4 KB block of 512 words
-            unsigned long long *p = nullptr;
+        if (f == t.free_words.size()) {  // a 4 KB block of 512 pairs
+            unsigned *p = nullptr;
             MIL_HIP(hipMalloc((void **)&p, 4096));
-            for (int i = 511; i >= 0; --i) t.free_words.push_back(TicketWord{key.dev, p + i, 0u});
+            for (int i = 511; i >= 0; --i) t.free_words.push_back(TicketWord{key.dev, p + 2 * i, 0u, true});
             f = t.free_words.size() - 1;
         }
         it = t.slots.emplace(key, t.free_words[f]).first;
         t.free_words.erase(t.free_words.begin() + (long)f);
     }
     TicketWord &w = it->second;
-    const bool fresh = w.epoch == 0;
-    if (++w.epoch == 0) w.epoch = 1;  // wrapped
-    if (fresh || w.epoch == 1 || capture != hipStreamCaptureStatusNone) MIL_HIP(hipMemsetAsync(w.p, 0, sizeof(unsigned long long), s));
-    return Ticket{w.p, w.epoch};
+    const bool captured = capture != hipStreamCaptureStatusNone;
+    unsigned *cur = w.p + (w.launches & 1u), *next = w.p + ((w.launches + 1u) & 1u);
+    ++w.launches;
+    if (w.fresh) MIL_HIP(hipMemsetAsync(w.p, 0, 2 * sizeof(unsigned), s));
+    else if (captured) MIL_HIP(hipMemsetAsync(cur, 0, sizeof(unsigned), s));
+    w.fresh = false;
+    return Ticket{cur, next, captured};
 }
 
 }  // namespace
@@ -606,7 +610,7 @@ void release_march_ticket(hipStream_t s) {
     std::lock_guard<std::mutex> g(t.mu);
     for (auto it = t.slots.begin(); it != t.slots.end();) {
         if (it->first.s == s) {
-            t.free_words.push_back(it->second);  // with its epoch: the next owner continues above what the word holds
+            t.free_words.push_back(it->second);  // with its launch count: the next owner continues the alternation
             it = t.slots.erase(it);
         } else {
             ++it;
@@ -640,16 +644,18 @@ void affine_resample_march(float *out, const float *src, Dims o, Dims sd, const 
     a.gy = ((march_y ? a.tz : a.ty) + kWaves - 1) / kWaves;
     const unsigned long long pieces = (unsigned long long)a.gx * a.gy * ((run_len + kPiece - 1) / kPiece);
     if (pieces > 0x7fffffffull) throw Error(-1, "affine_resample: volume exceeds launch limits");
+    std::lock_guard<std::mutex> queue_order(tickets().mu);
     const Ticket ticket = ticket_of(s);
-    auto launch = [&](auto kern, int which) {
-        const unsigned wgs = march_grid(kern, which, pieces * kPiece);
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), 0, s, out, src, a, ticket.p, ticket.epoch, run_len);
+    const unsigned wgs = march_grid(pieces * kPiece);
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(kThreads), 0, s, out, src, a, ticket.cur, ticket.next, run_len);
     };
-    if (march_y && strict_window) launch(resample_march_kernel<true, true>, 0);
-    else if (march_y) launch(resample_march_kernel<true, false>, 1);
-    else if (strict_window) launch(resample_march_kernel<false, true>, 2);
-    else launch(resample_march_kernel<false, false>, 3);
+    if (march_y && strict_window) launch(resample_march_kernel<true, true>);
+    else if (march_y) launch(resample_march_kernel<true, false>);
+    else if (strict_window) launch(resample_march_kernel<false, true>);
+    else launch(resample_march_kernel<false, false>);
     MIL_HIP(hipGetLastError());
+    if (ticket.captured) MIL_HIP(hipMemsetAsync(ticket.cur, 0, sizeof(unsigned), s));  // a replay leaves both words zero
 }
 
 // MIL_MIP3D_V2=0 keeps resample_mip_kernel (affine.hip) for comparisons.

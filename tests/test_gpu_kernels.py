@@ -323,6 +323,62 @@ def test_marching_resample_equals_the_one_voxel_kernel(dev, monkeypatch):
     assert len(cases) > 80
 
 
+def test_marching_resample_ticket_counters_across_streams_and_graph_replays(dev):
+    """The marching resample hands its pieces out through a pair of counters per stream (csrc/resample_march.hip: launch n
+    draws from word n % 2 and zeroes the other one for its successor; memset nodes around a launch that is captured into a
+    graph).  Back-to-back launches with different grids on two streams, a captured launch replayed between eager ones: every
+    output -- written into buffers full of NaN -- equals the first eager result bit for bit."""
+    import torch
+    rng = np.random.default_rng(11)
+    shape = (48, 64, 256)
+    src = T(rng.standard_normal(shape).astype(f32))
+    m1 = np.array([1, 0, 0, 0.5, 0, 1, 0, -0.25, 0, 0, 1, 0.75], dtype=f32)
+    c, s_ = np.cos(np.deg2rad(3.0)), np.sin(np.deg2rad(3.0))
+    m2 = np.array([c, 0, -s_, 4, 0, 1, 0, 0, s_, 0, c, -3], dtype=f32)
+    small = (16, 32, 128)
+    want1, want2, want3 = dev.affine_resample(src, m1, shape), dev.affine_resample(src, m2, shape), dev.affine_resample(src, m1, small)
+    torch.cuda.synchronize()
+
+    def same(a, b):
+        return torch.equal(a.view(torch.int32), b.view(torch.int32))
+    lib = dev._lib.load()
+
+    def into(out, m, stream):  # resample into a caller's buffer (pre-filled with NaN) on `stream`
+        mm = np.ascontiguousarray(m, dtype=f32)
+        rc = lib.mil_affine_resample(out.data_ptr(), src.data_ptr(), out.shape[2], out.shape[1], out.shape[0], shape[2], shape[1],
+                                     shape[0], mm.ctypes.data_as(dev._lib.c_float_p), stream.cuda_stream)
+        assert rc == 0
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for k in range(7):  # alternating grids on two streams, no host sync in between
+        for st, m, w, shp in ((s1, m1, want1, shape), (s2, m2, want2, shape), (s1, m1, want3, small), (s2, m1, want1, shape)):
+            o = torch.full(shp, float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.current_stream().synchronize()
+            into(o, m, st)
+            outs.append((o, w))
+    torch.cuda.synchronize()
+    assert all(same(o, w) for o, w in outs)
+    # a captured launch, replayed between eager launches of either parity on the same stream
+    g = torch.cuda.CUDAGraph()
+    gout = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s1):
+        into(gout, m2, s1)
+    torch.cuda.synchronize()
+    for k in range(5):
+        gout.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            g.replay()
+            for j in range(k % 3):  # 0, 1 or 2 eager launches between replays: both parities meet a replayed word
+                o = torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+                into(o, m1, s1)
+                outs.append((o, want1))
+        torch.cuda.synchronize()
+        assert same(gout, want2), k
+    assert all(same(o, w) for o, w in outs)
+
+
 def test_resample_of_planes_beyond_2_to_23_voxels(dev, monkeypatch):
     """fetch_linear_small forms its offsets with UNSIGNED 24-bit multiplies: a source whose planes hold 2^23 .. 2^24 voxels
     (4096 x 2048) must resample exactly like the 64-bit address path (MIL_RESAMPLE_SMALL=0) -- the signed multiply read such
