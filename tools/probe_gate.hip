@@ -38,6 +38,64 @@ __global__ void work_kernel(const float *data, int spins, float m0, const Mail *
     }
 }
 
+// D: the gate COPIES the matrix into device memory once it is released; the work kernel reads it from there (B and C let every
+//    wave of the work kernel read mail->m[0] from host memory: 6 144 uncached reads over PCIe -- that, not the waiting, is
+//    their 0.6 ms)
+__global__ void gate_copy_kernel(const Mail *mail, unsigned long long want, float *d_m, int *timed_out) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&mail->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        if (wall_clock64() - t0 > 100000000ull) {
+            *timed_out = 1;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (threadIdx.x < 12) d_m[threadIdx.x] = mail->m[threadIdx.x];
+}
+__global__ void work_dev_kernel(const float *data, int spins, const float *d_m, volatile double *host, double ticket) {
+    float acc = d_m[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)spins) __builtin_amdgcn_s_sleep(8);
+        host[0] = (double)acc + data[0];
+        __threadfence_system();
+        host[1] = ticket;
+    }
+}
+// E: ONE kernel per evaluation, pre-queued: workgroup 0 waits for the release, copies the matrix into device memory and raises a
+//    device flag (agent scope); every other workgroup spins on that flag (L2, not PCIe)
+__global__ void work_gated_kernel(const float *data, int spins, const Mail *mail, unsigned long long want, float *d_m,
+                                  unsigned long long *d_flag, volatile double *host, double ticket, int *timed_out) {
+    __shared__ float m0;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        if (blockIdx.x == 0) {
+            while (__hip_atomic_load(&mail->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+                if (wall_clock64() - t0 > 100000000ull) { *timed_out = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            for (int i = 0; i < 12; ++i) __hip_atomic_store(d_m + i, mail->m[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(d_flag, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(d_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (wall_clock64() - t0 > 100000000ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        m0 = __hip_atomic_load(d_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    float acc = m0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)spins) __builtin_amdgcn_s_sleep(8);
+        host[0] = (double)acc + data[0];
+        __threadfence_system();
+        host[1] = ticket;
+    }
+}
+
 __global__ void gate_kernel(const Mail *mail, unsigned long long want, int *timed_out) {
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&mail->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
@@ -128,6 +186,53 @@ int main() {
         }
         const double c = std::chrono::duration<double>(now() - t0).count() / N * 1e6;
         CHECK(hipStreamSynchronize(s));
+        // ---- D: gate kernel that copies the matrix to device memory
+        float *d_m;
+        unsigned long long *d_flag;
+        CHECK(hipMalloc(&d_m, 64));
+        CHECK(hipMalloc(&d_flag, 8));
+        CHECK(hipMemset(d_flag, 0, 8));
+        mail->ticket = 0;
+        host[1] = 0;
+        ticket = 0;
+        rel = 0;
+        hipLaunchKernelGGL(gate_copy_kernel, dim3(1), dim3(64), 0, s, (const Mail *)mail, 1ull, d_m, d_to);
+        hipLaunchKernelGGL(work_dev_kernel, dim3(1536), dim3(256), 0, s, d_data, spins, (const float *)d_m, host, 1.0);
+        t0 = now();
+        for (int i = 0; i < N; ++i) {
+            ticket += 1;
+            mail->m[0] = (float)i;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            mail->ticket = ++rel;
+            if (i + 1 < N) {
+                hipLaunchKernelGGL(gate_copy_kernel, dim3(1), dim3(64), 0, s, (const Mail *)mail, rel + 1, d_m, d_to);
+                hipLaunchKernelGGL(work_dev_kernel, dim3(1536), dim3(256), 0, s, d_data, spins, (const float *)d_m, host, ticket + 1);
+            }
+            wait_ticket(ticket);
+        }
+        const double d = std::chrono::duration<double>(now() - t0).count() / N * 1e6;
+        CHECK(hipStreamSynchronize(s));
+        // ---- E: the gate inside the work kernel
+        mail->ticket = 0;
+        host[1] = 0;
+        ticket = 0;
+        rel = 0;
+        hipLaunchKernelGGL(work_gated_kernel, dim3(1536), dim3(256), 0, s, d_data, spins, (const Mail *)mail, 1ull, d_m, d_flag, host, 1.0, d_to);
+        t0 = now();
+        for (int i = 0; i < N; ++i) {
+            ticket += 1;
+            mail->m[0] = (float)i;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            mail->ticket = ++rel;
+            if (i + 1 < N)
+                hipLaunchKernelGGL(work_gated_kernel, dim3(1536), dim3(256), 0, s, d_data, spins, (const Mail *)mail, rel + 1, d_m, d_flag, host, ticket + 1, d_to);
+            wait_ticket(ticket);
+        }
+        const double e5 = std::chrono::duration<double>(now() - t0).count() / N * 1e6;
+        CHECK(hipStreamSynchronize(s));
+        printf("kernel body %4d us: D gate kernel copies the matrix to device memory %.2f us | E gate inside the work kernel %.2f us per dependent evaluation\n", spins / 100, d, e5);
+        CHECK(hipFree(d_m));
+        CHECK(hipFree(d_flag));
         int to = 0;
         CHECK(hipMemcpy(&to, d_to, 4, hipMemcpyDeviceToHost));
         printf("kernel body %4d us: A launch after poll %.2f us | B pre-queued behind hipStreamWaitValue64 %.2f us | C pre-queued behind a gate "
