@@ -1049,8 +1049,14 @@ constexpr unsigned kMinChunk = 24;
 constexpr unsigned kChunkCus = 256;
 // workgroups (of four waves) per compute unit, by kernel 3 .. 6 (ms per evaluation at 512 x 512 x 256, identity / 3 deg about
 // y + 2 %, profiles/r05/reg_cost_chunked_ab.txt: kernel 3 with 4 | 5 | 6: 0.146 | 0.146 | 0.142; kernel 5: 0.156 | 0.169 | 0.163
-// at the identity, 0.176 | 0.183 | 0.180; kernel 6: 0.167 | 0.1645 | 0.170 at 3 deg + 2 %)
-constexpr int kChunkWgsPerCu[4] = {6, 0, 4, 5};
+// at the identity, 0.176 | 0.183 | 0.180; kernel 6: 0.167 | 0.1645 | 0.170 at 3 deg + 2 %).  Round 6: the plain-layout kernels
+// (3 and 6) run TWELVE workgroups per compute unit -- twice what is resident, pieces of ~43 steps -- so that the dispatcher
+// hands the second half of the pieces to whichever slots free first: what a piece costs depends on where it lies (rim,
+// re-gathers, what its neighbours left in L2), and with one piece per resident workgroup the evaluation ends with the slowest
+// one.  profiles/r06/reg_cost_chunk_grid.txt: kernel 3 at the identity 0.1289 (6) -> 0.1233 (12), kernel 6 at 3 deg + 2 %
+// 0.1484 (5) -> 0.1400 (12), at 10 deg 0.205 -> 0.192; the row-pair kernel (5) is best at 4 - 5 and stays.  Static pieces:
+// the partial sums and their order are fixed by the grid, as before.
+constexpr int kChunkWgsPerCu[4] = {12, 0, 4, 12};
 unsigned chunk_grid(int which, unsigned long long total_steps) {
     int per_cu = kChunkWgsPerCu[which & 3];
     if (const int forced = g_chunk_wgs_per_cu.load(std::memory_order_relaxed)) per_cu = forced;  // experiments
