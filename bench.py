@@ -322,8 +322,8 @@ def auxiliary_kernels(torch, mdev, eng, img, psf):
         return lambda: mdev._check(lib.mil_affine_resample(dst.data_ptr(), img.data_ptr(), nx, ny, nz, nx, ny, nz,
                                                            mm.ctypes.data_as(mdev._lib.c_float_p),
                                                            int(torch.cuda.current_stream().cuda_stream)), "mil_affine_resample")
-    out["resample_identity"] = row("resample_march_kernel<false, false>", timed(torch, resample(ident)), 2 * R, "affineTransform, read R + write R")
-    out["resample_3deg_2pct"] = row("resample_march_kernel<true, false>", timed(torch, resample(m3)), 2 * R, "rotation 3 deg about y, scale 1.02, shift")
+    out["resample_identity"] = row("resample_march_kernel<false, false>", timed(torch, resample(ident), reps=20), 2 * R, "affineTransform, read R + write R")
+    out["resample_3deg_2pct"] = row("resample_march_kernel<true, false>", timed(torch, resample(m3), reps=20), 2 * R, "rotation 3 deg about y, scale 1.02, shift")
     # mip3dgpu: 36 x (resample into the rotated box + z projection), one fused kernel per angle: the box is never written, so
     # the bytes per angle are read R (source) + write the plane.  (The reference's two kernels move R + 2 boxes + the plane =
     # 1.6 GB per angle; on those bytes the same time would read 6.9 / 4.3 TB/s.)
