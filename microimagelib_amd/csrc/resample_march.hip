@@ -466,9 +466,14 @@ __global__ __launch_bounds__(kThreads) void mip_rot_x_kernel(int *__restrict__ o
         const unsigned dy = 4u * (unsigned)(Y.i1 - Y.i0) * (unsigned)a.sx, dz = 4u * (unsigned)(Z.i1 - Z.i0) * plane;
         const float wy0 = in ? Y.w0 : 0.0f, wy1 = in ? Y.w1 : 0.0f, wz0 = in ? Z.w0 : 0.0f, wz1 = in ? Z.w1 : 0.0f;
         const int n = min(64, z1 - zb);
-        for (int i0 = 0; i0 < n; i0 += 4) {  // four steps per trip (a step beyond z1 has zero weights: its value is 0)
+        // eight steps (32 row loads) per trip: the waves spend 62 % of their cycles waiting for loads (profiles/r06/aux_pmc.json);
+        // 4 / 8 / 16 steps per trip: 2.74 / 2.68 / 3.49 ms per 36-angle series about x (profiles/r06/mip3d_grid.txt)
+#ifndef MIP_STEPS_PER_TRIP
+#define MIP_STEPS_PER_TRIP 8
+#endif
+        for (int i0 = 0; i0 < n; i0 += MIP_STEPS_PER_TRIP) {  // steps per trip (a step beyond z1 has zero weights: its value is 0)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < MIP_STEPS_PER_TRIP; ++k) {
                 const int i = i0 + k;
                 const unsigned s00 = __builtin_amdgcn_readlane(o00, i);
                 const unsigned sdy = __builtin_amdgcn_readlane(dy, i), sdz = __builtin_amdgcn_readlane(dz, i);
@@ -682,7 +687,13 @@ void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims sd, cons
     int *o = reinterpret_cast<int *>(out_plane);
     static const bool no_rot_x = getenv("MIL_MIP3D_ROTX") && getenv("MIL_MIP3D_ROTX")[0] == '0';
     if (skip == 1 && a.m[4] == 0.0f && a.m[8] == 0.0f && !no_rot_x) {  // a rotation about x: the wave-uniform form
-        a.segments = std::max(1, std::min(8, a.tz / 128));
+        // z segments of >= 64 steps (eight for the 572 steps of a 512 x 512 x 256 volume's rotated box): 4 576 workgroups were 2.2
+        // rounds of what the chip holds, the last one a quarter full; 192 / 128 / 64 / 36 steps per segment: 2.77 / 2.68 / 2.53 /
+        // 2.53 ms per series about x, 3.21 / 3.12 / 2.97 / 2.97 about y (profiles/r06/mip3d_grid.txt)
+#ifndef MIP_SEG_STEPS
+#define MIP_SEG_STEPS 64
+#endif
+        a.segments = std::max(1, std::min(16, a.tz / MIP_SEG_STEPS));
         dim3 gridx((a.tx + 63) / 64, (a.ty + kWaves - 1) / kWaves, a.segments);
         hipLaunchKernelGGL(mip_rot_x_kernel, gridx, dim3(kThreads), 0, s, o, src, a);
         MIL_HIP(hipGetLastError());
