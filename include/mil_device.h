@@ -84,7 +84,7 @@ void mil_dev_free(void *d_ptr);
 int mil_host_alloc(void **h_ptr, size_t bytes);    /* pinned */
 void mil_host_free(void *h_ptr);
 int mil_stream_create(void **stream);              /* non-blocking */
-void mil_stream_destroy(void *stream);
+void mil_stream_destroy(void *stream);             /* waits for the work queued on it */
 int mil_stream_sync(void *stream);
 int mil_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);     /* asynchronous on `stream` */
 int mil_download(void *h_dst, const void *d_src, size_t bytes, void *stream);

@@ -205,6 +205,9 @@ int mil_stream_create(void **stream) {
 }
 void mil_stream_destroy(void *stream) {
     if (!stream) return;
+    // the stream's resample counters go to the next stream that asks: not before the last launch that uses them has finished
+    // (hipStreamDestroy alone returns while work is still queued)
+    (void)hipStreamSynchronize(as_stream(stream));
     k::release_march_ticket(as_stream(stream));
     (void)hipStreamDestroy(as_stream(stream));
 }

@@ -594,6 +594,28 @@ def test_texture_weight_emulation_switch(dev, api):
     assert np.array_equal(again.view(np.uint32), exact.view(np.uint32)) and dev.corr_sums(dt, ds, m) == exact_sums
 
 
+def test_reg3d_on_a_ragged_width_takes_the_same_path_as_the_one_voxel_kernels(api, dev):
+    """A target 250 voxels wide -- not a multiple of 128 -- runs the chunked two-voxel cost kernels with the lanes beyond the row
+    kept out of the sums (csrc/corr_padded.hip, RAGGED; round 6); until then such volumes fell back to the one-voxel tiled kernels
+    (forced here: kernel 0).  Same voxels, same float32 values, float64 sums within 1e-15: the whole 6 -> 12-DOF cascade must
+    make the same number of evaluations and return the same matrix and the same registered volume, bit for bit."""
+    rng = np.random.default_rng(21)
+    shape = (24, 40, 250)
+    tgt = do.blob_volume(shape, n_blobs=40, seed=5) + rng.normal(0, 1.0, shape).astype(f32)
+    m = ro.dof9tomatrix(np.array([0, 1.5, -0.8, 0.6, 1.2, -0.7, 2.0, 1.01, 0.99, 1.0], dtype=f32), 9)
+    src = ro.affine_transform(tgt, m, shape) + rng.normal(0, 1.0, shape).astype(f32)
+    dev.corr_padded_force_kernel(0)
+    try:
+        want = api.reg3d(tgt, src, reg_choice=2, aff_method=6)
+    finally:
+        dev.corr_padded_force_kernel(-1)
+    got = api.reg3d(tgt, src, reg_choice=2, aff_method=6)
+    assert got[2][5] == want[2][5] and got[2][5] > 100, (got[2][5], want[2][5])  # evaluations
+    assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), (got[1], want[1])
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    assert got[2][3] > 0.5, got[2]  # and it did register (final ZNCC)
+
+
 def test_fenced_and_fence_free_tails_agree(dev, monkeypatch):
     """The cost kernels hand their partial sums from workgroup to workgroup with agent-scope (sc1) stores / loads and
     `s_waitcnt vmcnt(0)` instead of release / acquire fences (csrc/corr_finish.h).  MIL_CORR_FENCES=1 adds the fences:
