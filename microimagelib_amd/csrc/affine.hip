@@ -281,9 +281,9 @@ void affine_resample(float *out, const float *src, Dims out_dims, Dims src_dims,
     MIL_HIP(hipGetLastError());
 }
 
-void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s) {
+void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s, bool plane_is_zero) {
     if (resample_mip2_eligible(box, src_dims)) {  // taps under exact zero weights left out, z range clipped (resample_march.hip)
-        resample_mip2_z(out_plane, src, box, src_dims, m, s);
+        resample_mip2_z(out_plane, src, box, src_dims, m, s, plane_is_zero);
         return;
     }
     AffineArgs a = make_args(box, src_dims, m);
@@ -294,7 +294,7 @@ void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims,
     const int segments = std::max(1, std::min(4, a.tz / (lz * 32)));
     dim3 grid((a.tx + lx - 1) / lx, (a.ty + kTileY - 1) / kTileY, segments);
     if (grid.y > 65535) throw Error(-1, "resample_mip_z: plane exceeds launch limits");
-    MIL_HIP(hipMemsetAsync(out_plane, 0, (size_t)a.tx * a.ty * sizeof(float), s));
+    if (!plane_is_zero) MIL_HIP(hipMemsetAsync(out_plane, 0, (size_t)a.tx * a.ty * sizeof(float), s));
     int *o = reinterpret_cast<int *>(out_plane);
 #define MIL_MIP(LX)                                                                                                   \
     if (small_source(src_dims)) hipLaunchKernelGGL((resample_mip_kernel<LX, true>), grid, dim3(kBlockThreads), 0, s, o, src, a, segments); \

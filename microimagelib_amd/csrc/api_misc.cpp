@@ -134,38 +134,56 @@ void mip_series(float *h_out, float *d_out, const float *d_img, Dims img, Dims r
     const size_t plane = (size_t)rot_box.nx * rot_box.ny;
     const char *e = getenv("MIL_MIP3D_FUSED");
     const bool fused = !(e && e[0] == '0');
-    DeviceBuffer<float> d_rot(fused ? 0 : (size_t)rot_box.count()), d_proj(d_out ? 0 : plane);
-    // rotations about y: the wave-uniform kernel on the transposed volume (k::mip_about_y_by_transpose); one transpose per series
+    // The planes of a series form ONE stack -- the caller's (device-pointer form) or a scratch one that goes to the host in a
+    // single copy -- zeroed by ONE memset: a memset per angle (36 fill kernels of ~5 us between kernels of ~65 us) was 4 - 7 % of
+    // a series (round 6, profiles/r06/mip3d_grid.txt).
+    DeviceBuffer<float> d_rot(fused ? 0 : (size_t)rot_box.count()), d_stack(d_out ? 0 : plane * (size_t)project_num);
+    float *stack = d_out ? d_out : d_stack.get();
+    std::vector<k::Affine12> mats((size_t)project_num), mats_t((size_t)project_num);
+    // rotations about y: the wave-uniform kernel on the transposed volume (k::mip_about_y_by_transpose): one transpose of the
+    // volume per series, the planes projected into a transposed stack, ONE transpose of that stack at the end
     const Dims img_t{img.ny, img.nx, img.nz}, box_t{rot_box.ny, rot_box.nx, rot_box.nz};
-    DeviceBuffer<float> d_img_t, d_plane_t;
+    std::vector<char> transposed((size_t)project_num, 0);  // per angle: the matrix has the form the transposed problem needs
+    bool any_transposed = false;
     for (long long i = 0; i < project_num; ++i) {
-        const float angle = project_step * (float)(int)i;
-        k::Affine12 m, mt;
-        rot2matrix(m.m, angle, img.nx, img.ny, img.nz, axis);
-        float *proj = d_out ? d_out + plane * (size_t)i : d_proj.get();
-        if (fused && axis == 2 && k::mip_about_y_by_transpose(m, rot_box, img, mt)) {
-            if (!d_img_t.get()) {
-                d_img_t.alloc((size_t)img.count());
-                d_plane_t.alloc(plane);
-                k::transpose_xy(d_img_t.get(), d_img, img, s);
-            }
-            k::resample_mip_z(d_plane_t.get(), d_img_t.get(), box_t, img_t, mt, s);
-            k::transpose_xy(proj, d_plane_t.get(), Dims{box_t.nx, box_t.ny, 1}, s);
-        } else if (fused) {
-            k::resample_mip_z(proj, d_img, rot_box, img, m, s);
-        } else {
-            k::affine_resample(d_rot.get(), d_img, rot_box, img, m, s);
-            k::max_projection(proj, d_rot.get(), rot_box, 1, s);
-        }
-        if (h_out) MIL_HIP(hipMemcpyAsync(h_out + plane * (size_t)i, proj, plane * sizeof(float), hipMemcpyDeviceToHost, s));
+        rot2matrix(mats[(size_t)i].m, project_step * (float)(int)i, img.nx, img.ny, img.nz, axis);
+        if (fused && axis == 2 && k::mip_about_y_by_transpose(mats[(size_t)i], rot_box, img, mats_t[(size_t)i]))
+            transposed[(size_t)i] = 1, any_transposed = true;
     }
+    DeviceBuffer<float> d_img_t, d_stack_t;
+    if (fused) {
+        float *target = stack;
+        if (any_transposed) {
+            d_img_t.alloc((size_t)img.count());
+            d_stack_t.alloc(plane * (size_t)project_num);
+            k::transpose_xy(d_img_t.get(), d_img, img, s);
+            target = d_stack_t.get();
+        }
+        MIL_HIP(hipMemsetAsync(target, 0, plane * (size_t)project_num * sizeof(float), s));
+        for (long long i = 0; i < project_num; ++i) {
+            if (transposed[(size_t)i]) k::resample_mip_z(target + plane * (size_t)i, d_img_t.get(), box_t, img_t, mats_t[(size_t)i], s, true);
+            else if (!any_transposed) k::resample_mip_z(target + plane * (size_t)i, d_img, rot_box, img, mats[(size_t)i], s, true);
+        }
+        if (any_transposed) {
+            // the planes of the other angles are zero in the transposed stack, so they arrive zeroed: projected in place now
+            k::transpose_xy(stack, target, Dims{box_t.nx, box_t.ny, project_num}, s);
+            for (long long i = 0; i < project_num; ++i)
+                if (!transposed[(size_t)i]) k::resample_mip_z(stack + plane * (size_t)i, d_img, rot_box, img, mats[(size_t)i], s, true);
+        }
+    } else {
+        for (long long i = 0; i < project_num; ++i) {
+            k::affine_resample(d_rot.get(), d_img, rot_box, img, mats[(size_t)i], s);
+            k::max_projection(stack + plane * (size_t)i, d_rot.get(), rot_box, 1, s);
+        }
+    }
+    if (h_out) MIL_HIP(hipMemcpyAsync(h_out, stack, plane * (size_t)project_num * sizeof(float), hipMemcpyDeviceToHost, s));
     MIL_HIP(hipStreamSynchronize(s));
     // the scratch buffers were only ever used on `s`: hand them back without a device-wide fence (another worker thread's
     // registration may be queued on its own stream of this device)
     d_rot.release_after(s);
-    d_proj.release_after(s);
+    d_stack.release_after(s);
     d_img_t.release_after(s);
-    d_plane_t.release_after(s);
+    d_stack_t.release_after(s);
 }
 
 // rotated box of mip3dgpu (src/apifunc.cpp:582-590): the rotation axis keeps its extent, the other two become the diagonal

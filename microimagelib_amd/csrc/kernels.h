@@ -96,7 +96,8 @@ void release_march_ticket(hipStream_t s);  // the stream is about to be destroye
 void affine_resample_march(float *out, const float *src, Dims out_dims, Dims src_dims, const Affine12 &m, hipStream_t s,
                            bool strict_window);
 bool resample_mip2_eligible(Dims box, Dims src);
-void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s);
+void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s,
+                     bool plane_is_zero = false);
 // mip3dgpu about y through the transposed volume (csrc/resample_march.hip): true if `m` is a rotation-series matrix about y
 // that the wave-uniform kernel can run on transpose_xy(src); `mt` = the matrix for the transposed problem (box and source with
 // x and y exchanged), whose plane comes out transposed
@@ -105,7 +106,9 @@ bool mip_about_y_by_transpose(const Affine12 &m, Dims box, Dims src_dims, Affine
 void transpose_xy(float *out, const float *in, Dims in_dims, hipStream_t s);
 // affine_resample into `box` followed by the maximum projection along z, fused: out_plane[box.ny][box.nx] (mip3dgpu's
 // inner pair, src/apifunc.cpp:610-613); same bits as the two kernels one after the other
-void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s);
+// plane_is_zero: the caller has zeroed the plane on `s` already (a whole stack of them at once: mip_series)
+void resample_mip_z(float *out_plane, const float *src, Dims box, Dims src_dims, const Affine12 &m, hipStream_t s,
+                    bool plane_is_zero = false);
 constexpr int kCorrCounters = 64;  // first-level completion counters of a cost kernel (+ 1 top-level)
 struct CorrTail {  // what the last workgroup of a cost kernel needs (corr_finish.h)
     double *partials;   // [2][nblocks]

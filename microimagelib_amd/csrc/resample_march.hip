@@ -670,7 +670,7 @@ bool resample_mip2_eligible(Dims box, Dims sd) {
     return small_source(sd) && box.nx > 0 && box.ny > 0 && box.nz > 0 && box.nx < (1 << 24) && box.ny < (1 << 24) && box.nz < (1 << 24);
 }
 
-void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims sd, const Affine12 &m, hipStream_t s) {
+void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims sd, const Affine12 &m, hipStream_t s, bool plane_is_zero) {
     MipArgs a;
     for (int i = 0; i < 12; ++i) a.m[i] = m.m[i];
     a.tx = (int)box.nx; a.ty = (int)box.ny; a.tz = (int)box.nz;
@@ -683,7 +683,7 @@ void resample_mip2_z(float *out_plane, const float *src, Dims box, Dims sd, cons
     a.segments = std::max(1, std::min(4, a.tz / (lz * 32)));
     dim3 grid((a.tx + lx - 1) / lx, (a.ty + kWaves - 1) / kWaves, a.segments);
     if (grid.y > 65535) throw Error(-1, "resample_mip_z: plane exceeds launch limits");
-    MIL_HIP(hipMemsetAsync(out_plane, 0, (size_t)a.tx * a.ty * sizeof(float), s));
+    if (!plane_is_zero) MIL_HIP(hipMemsetAsync(out_plane, 0, (size_t)a.tx * a.ty * sizeof(float), s));
     int *o = reinterpret_cast<int *>(out_plane);
     static const bool no_rot_x = getenv("MIL_MIP3D_ROTX") && getenv("MIL_MIP3D_ROTX")[0] == '0';
     if (skip == 1 && a.m[4] == 0.0f && a.m[8] == 0.0f && !no_rot_x) {  // a rotation about x: the wave-uniform form
