@@ -322,6 +322,7 @@ __global__ void crop_kernel(float *__restrict__ out, const float *__restrict__ i
 // what the chip holds, striding over (row, quad) items: the one-voxel kernels above launch a workgroup per half row (262 144
 // of them for a 512 x 512 x 256 box, 1 KB each) and sat at 0.38 of the HBM roofline (profiles/r05/aux_pmc.json).
 typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+typedef float f32x2_nt __attribute__((ext_vector_type(2)));
 template <bool PAD>
 __global__ __launch_bounds__(256) void geo_rows4_kernel(float *__restrict__ out, const float *__restrict__ in, Geo g) {
     const unsigned quads = (unsigned)g.fx / 4u;
@@ -331,19 +332,40 @@ __global__ __launch_bounds__(256) void geo_rows4_kernel(float *__restrict__ out,
         const unsigned row = (unsigned)(i / quads);
         const int y = (int)(row % (unsigned)g.fy), z = (int)(row / (unsigned)g.fy), x = (int)(4u * q);
         f32x4_nt v;
+        // four consecutive source voxels: one 16-byte or two 8-byte loads where the address allows (a 500-wide image centred in
+        // a 512-wide box starts 24 bytes into the quad grid: 8-byte aligned) -- four scalar loads per thread touch every source
+        // line four times (round 6: pad 0.146 -> see profiles/r06/pad_crop_vector_loads.txt)
+        auto quad = [](const float *p) {
+            f32x4_nt q;
+            const size_t a = reinterpret_cast<size_t>(p);
+            if ((a & 15) == 0) {
+                q = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(p));
+            } else if ((a & 7) == 0) {
+                const f32x2_nt lo = __builtin_nontemporal_load(reinterpret_cast<const f32x2_nt *>(p));
+                const f32x2_nt hi = __builtin_nontemporal_load(reinterpret_cast<const f32x2_nt *>(p + 2));
+                q.x = lo.x; q.y = lo.y; q.z = hi.x; q.w = hi.y;
+            } else {
+                q.x = __builtin_nontemporal_load(p);
+                q.y = __builtin_nontemporal_load(p + 1);
+                q.z = __builtin_nontemporal_load(p + 2);
+                q.w = __builtin_nontemporal_load(p + 3);
+            }
+            return q;
+        };
         if (PAD) {  // padstackgpukernel :700-737: edge replication
             const int iy = clampi(y - g.oy, 0, g.sy - 1), iz = clampi(z - g.oz, 0, g.sz - 1);
             const float *src = in + (size_t)g.sx * ((size_t)iy + (size_t)g.sy * iz);
-            v.x = __builtin_nontemporal_load(src + clampi(x - g.ox, 0, g.sx - 1));
-            v.y = __builtin_nontemporal_load(src + clampi(x + 1 - g.ox, 0, g.sx - 1));
-            v.z = __builtin_nontemporal_load(src + clampi(x + 2 - g.ox, 0, g.sx - 1));
-            v.w = __builtin_nontemporal_load(src + clampi(x + 3 - g.ox, 0, g.sx - 1));
+            const int x0 = x - g.ox;
+            if (x0 >= 0 && x0 + 3 < g.sx) {
+                v = quad(src + x0);
+            } else {
+                v.x = __builtin_nontemporal_load(src + clampi(x0, 0, g.sx - 1));
+                v.y = __builtin_nontemporal_load(src + clampi(x0 + 1, 0, g.sx - 1));
+                v.z = __builtin_nontemporal_load(src + clampi(x0 + 2, 0, g.sx - 1));
+                v.w = __builtin_nontemporal_load(src + clampi(x0 + 3, 0, g.sx - 1));
+            }
         } else {    // cropgpukernel :740-753 (the crop lies inside the box: host check)
-            const float *src = in + (size_t)(x + g.ox) + (size_t)g.sx * ((size_t)(y + g.oy) + (size_t)g.sy * (z + g.oz));
-            v.x = __builtin_nontemporal_load(src);
-            v.y = __builtin_nontemporal_load(src + 1);
-            v.z = __builtin_nontemporal_load(src + 2);
-            v.w = __builtin_nontemporal_load(src + 3);
+            v = quad(in + (size_t)(x + g.ox) + (size_t)g.sx * ((size_t)(y + g.oy) + (size_t)g.sy * (z + g.oz)));
         }
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4_nt *>(out + (size_t)x + (size_t)g.fx * ((size_t)y + (size_t)g.fy * z)));
     }
@@ -465,7 +487,16 @@ __global__ void max_projection_kernel(float *__restrict__ out, const float *__re
         if (row >= (long long)sy * sz) return;
         const float *p = in + (size_t)row * sx;
         float a = 0.0f;
-        for (int x = lane; x < sx; x += 64) { const float v = p[x]; a = (a > v) ? a : v; }
+        if ((sx & 3) == 0 && (reinterpret_cast<size_t>(in) & 15) == 0) {  // 16 bytes per lane: two loads for a 512-wide row instead of eight
+            const float4 *p4 = reinterpret_cast<const float4 *>(p);
+            for (int x = lane; x < sx / 4; x += 64) {
+                const float4 v = p4[x];
+                const float m0 = (v.x > v.y) ? v.x : v.y, m1 = (v.z > v.w) ? v.z : v.w, m = (m0 > m1) ? m0 : m1;
+                a = (a > m) ? a : m;
+            }
+        } else {
+            for (int x = lane; x < sx; x += 64) { const float v = p[x]; a = (a > v) ? a : v; }
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const float v = __shfl_down(a, off, 64); a = (a > v) ? a : v; }
         if (lane == 0) out[row] = a;
