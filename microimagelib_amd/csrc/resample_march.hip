@@ -557,6 +557,8 @@ struct TicketWord {
     unsigned *p = nullptr;   // the pair
     unsigned launches = 0;   // queued on the pair so far
     bool fresh = true;       // never used: contents undefined
+    bool captured = false;   // a graph holds launches on this pair: it may replay them after the stream is gone, so the pair is
+                             // never handed to another stream (8 bytes stay behind)
 };
 struct TicketTable {
     std::mutex mu;
@@ -590,7 +592,7 @@ Ticket ticket_of(hipStream_t s) {
         if (f == t.free_words.size()) {  // a 4 KB block of 512 pairs
             unsigned *p = nullptr;
             MIL_HIP(hipMalloc((void **)&p, 4096));
-            for (int i = 511; i >= 0; --i) t.free_words.push_back(TicketWord{key.dev, p + 2 * i, 0u, true});
+            for (int i = 511; i >= 0; --i) t.free_words.push_back(TicketWord{key.dev, p + 2 * i, 0u, true, false});
             f = t.free_words.size() - 1;
         }
         it = t.slots.emplace(key, t.free_words[f]).first;
@@ -603,6 +605,7 @@ Ticket ticket_of(hipStream_t s) {
     if (w.fresh) MIL_HIP(hipMemsetAsync(w.p, 0, 2 * sizeof(unsigned), s));
     else if (captured) MIL_HIP(hipMemsetAsync(cur, 0, sizeof(unsigned), s));
     w.fresh = false;
+    w.captured = w.captured || captured;
     return Ticket{cur, next, captured};
 }
 
@@ -615,7 +618,7 @@ void release_march_ticket(hipStream_t s) {
     std::lock_guard<std::mutex> g(t.mu);
     for (auto it = t.slots.begin(); it != t.slots.end();) {
         if (it->first.s == s) {
-            t.free_words.push_back(it->second);  // with its launch count: the next owner continues the alternation
+            if (!it->second.captured) t.free_words.push_back(it->second);  // with its launch count: the next owner continues the alternation
             it = t.slots.erase(it);
         } else {
             ++it;
